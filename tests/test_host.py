@@ -1,0 +1,113 @@
+"""Host logic: PDB parsing, batch packing, mutation lists, weight formats.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from thermompnn_amd import pdb_io, ssm, weights
+from thermompnn_amd.datasets import ALPHABET, Mutation
+from thermompnn_amd.synthetic import synthetic_pdb_dict
+
+PDB = os.path.join(GOLDEN, "2OCJ.pdb")
+GAP = os.path.join(GOLDEN, "2OCJ_gap_chainA.pdb")
+
+
+@pytest.mark.parametrize("tag,path,chains", [("A", PDB, "A"), ("AB", PDB, ["A", "B"]), ("gapA", GAP, "A")])
+def test_parser_matches_reference(tag, path, chains):
+    pg = load_golden("parser_2OCJ")
+    d = pdb_io.alt_parse_PDB(path, chains)[0]
+    assert d["seq"] == str(pg[tag + "_seq"])
+    assert d["resn_list"] == [str(x) for x in pg[tag + "_resn_list"]]
+    assert d["num_of_chains"] == int(pg[tag + "_num_of_chains"])
+    for ch in chains:
+        for atom, v in d["coords_chain_" + ch].items():
+            np.testing.assert_array_equal(np.asarray(v), pg[f"{tag}_{atom}"])
+    assert d["name"] == os.path.basename(path)[:-4]
+
+
+def test_parser_missing_chain_is_skipped():
+    d = pdb_io.alt_parse_PDB(PDB, "AZ")[0]
+    assert d["num_of_chains"] == 1 and "seq_chain_Z" not in d
+    assert d["resn_list"] == list("no_chain")     # reference quirk (protein_mpnn_utils.py:279-280,346)
+
+
+def test_mse_and_insertion_codes(tmp_path):
+    lines = [
+        "ATOM      1  N   ALA A   1      0.000   0.000   0.000  1.00  0.00           N",
+        "ATOM      2  CA  ALA A   1      1.458   0.000   0.000  1.00  0.00           C",
+        "ATOM      3  C   ALA A   1      2.009   1.420   0.000  1.00  0.00           C",
+        "ATOM      4  O   ALA A   1      1.251   2.390   0.000  1.00  0.00           O",
+        "HETATM    5  N   MSE A   2      3.332   1.536   0.000  1.00  0.00           N",
+        "HETATM    6  CA  MSE A   2      3.988   2.839   0.000  1.00  0.00           C",
+        "HETATM    7  C   MSE A   2      5.504   2.693   0.000  1.00  0.00           C",
+        "HETATM    8  O   MSE A   2      6.030   1.580   0.000  1.00  0.00           O",
+        "ATOM      9  CA  GLY A   2A     7.000   3.000   0.000  1.00  0.00           C",
+        "ATOM     10  CA  GLY A   2A     9.000   9.000   9.000  1.00  0.00           C",
+        "ATOM     11  CA  UNK A   5      8.000   4.000   0.000  1.00  0.00           C",
+    ]
+    p = tmp_path / "toy1.pdb"
+    p.write_text("\n".join(lines) + "\n")
+    d = pdb_io.alt_parse_PDB(str(p), "A")[0]
+    assert d["seq"] == "AMG---"          # MSE->M, insertion code sorted after '', gaps 3,4, UNK -> '-'
+    ca = np.asarray(d["coords_chain_A"]["CA_chain_A"])
+    assert ca[2].tolist() == [7.0, 3.0, 0.0]                  # first occurrence of an atom wins
+    assert np.isnan(np.asarray(d["coords_chain_A"]["N_chain_A"])[2]).all()
+    assert d["resn_list"] == ["1", "2", "2A", "5"] and d["name"] == "toy1"
+
+
+def test_tied_featurize_tuple():
+    g = load_golden("2OCJ_A_gap")
+    d = pdb_io.alt_parse_PDB(GAP, "A")
+    out = pdb_io.tied_featurize(d, "cpu", None)
+    assert len(out) == 20
+    X, S, mask, lengths, chain_M, chain_enc = out[:6]
+    residue_idx = out[12]
+    np.testing.assert_array_equal(X[0].numpy(), g["X"])
+    np.testing.assert_array_equal(S[0].numpy(), g["S"])
+    np.testing.assert_array_equal(mask[0].numpy(), g["mask"])
+    np.testing.assert_array_equal(residue_idx[0].numpy(), g["residue_idx"])
+    np.testing.assert_array_equal(chain_enc[0].numpy(), g["chain_enc"])
+    assert S.dtype == torch.int64 and X.dtype == torch.float32 and lengths.dtype == np.int32
+    assert chain_M.sum() == len(g["S"])
+    with pytest.raises(NotImplementedError):
+        pdb_io.tied_featurize(d, "cpu", None, pssm_dict={})
+
+
+def test_tied_featurize_two_chains_and_padding():
+    a = pdb_io.alt_parse_PDB(PDB, ["A", "B"])[0]
+    b = synthetic_pdb_dict(40, seed=1)
+    b["seq_chain_B"], b["coords_chain_B"] = b["seq_chain_A"], {k.replace("_A", "_B"): v for k, v in b["coords_chain_A"].items()}
+    X, S, mask, lengths, chain_M, chain_enc, *rest = pdb_io.tied_featurize([a, b], "cpu", None)
+    residue_idx = rest[6]
+    assert X.shape == (2, 388, 4, 3) and lengths.tolist() == [388, 40]
+    assert chain_enc[0, 193] == 1 and chain_enc[0, 194] == 2
+    assert residue_idx[0, 194] == 100 + 194                     # 100*(c-1)+position (:473)
+    assert mask[1, 80:].sum() == 0 and residue_idx[1, -1] == -100
+
+
+def test_ssm_mutation_list_and_asserts():
+    pdb = {"seq": "AC-W", "name": "toy"}
+    m = ssm.get_ssm_mutations(pdb)
+    assert len(m) == 61 and m[40] is None and m[0] == "A0A" and m[19] == "A0Y" and m[41] == "W3A"
+    objs = ssm.mutation_objects(pdb)
+    assert objs[40] is None and objs[41] == Mutation(3, "W", "A", None, "toy")
+    with pytest.raises(AssertionError, match="invalid, please try again"):
+        ssm.mutation_objects(pdb, ["B0A"])
+    assert ALPHABET[:-1] == "ACDEFGHIKLMNPQRSTVWY"
+
+
+def test_weight_formats_roundtrip(tmp_path):
+    sd = weights.synthetic_state_dict(3)
+    assert len(sd) == 130 and sum(v.numel() for v in sd.values()) == 4342876
+    mp, hd = weights.split_transfer_state_dict(sd)
+    assert len(mp) == 118 and sum(v.numel() for v in mp.values()) == 1660485
+    weights.save_vanilla_checkpoint(tmp_path / "v.pt", mp, 48)
+    k, back = weights.load_vanilla_checkpoint(tmp_path / "v.pt")
+    assert k == 48 and all(torch.equal(back[n], mp[n]) for n in mp)
+    weights.save_lightning_checkpoint(tmp_path / "t.ckpt", sd)
+    back = weights.load_thermompnn_checkpoint(tmp_path / "t.ckpt")
+    assert list(back) == list(sd) and all(torch.equal(back[n], sd[n]) for n in sd)
+    assert torch.equal(weights.synthetic_state_dict(3)["both_out.1.weight"], sd["both_out.1.weight"])
+    assert (sd["light_attention.feature_convolution.weight"] != 0).all()

@@ -1,0 +1,83 @@
+"""Pins oracle/thermompnn_oracle.py against vectors produced by the imported reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import thermompnn_oracle as orc
+
+CASES = ["2OCJ_A", "2OCJ_A_gap", "2OCJ_AB", "syn_L32", "syn_L256"]
+TOL_INTERMEDIATE = 1e-5   # abs, SURVEY §8c
+TOL_DDG = 1e-4            # kcal/mol, BASELINE.json north_star
+
+
+def inputs(g):
+    t = torch.from_numpy
+    return (t(g["X"])[None], t(g["S"].astype(np.int64))[None], t(g["mask"])[None],
+            torch.ones(1, len(g["S"])), t(g["residue_idx"].astype(np.int64))[None],
+            t(g["chain_enc"].astype(np.int64))[None])
+
+
+def neighbour_sets_equal(a, b, mask):
+    for i in np.nonzero(mask > 0)[0]:
+        if sorted(a[i].tolist()) != sorted(b[i].tolist()):
+            return False
+    return True
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference(case, synthetic_weights):
+    g = load_golden(case)
+    assert int(g["weight_seed"]) == 0
+    X, S, mask, chain_M, ridx, cenc = inputs(g)
+    tr = {}
+    with torch.no_grad():
+        ddg = orc.ssm_table(synthetic_weights, X, S, mask, chain_M, ridx, cenc, 48, trace=tr)[0].numpy()
+    assert neighbour_sets_equal(tr["E_idx"][0].numpy(), g["E_idx"], g["mask"])
+    # rows whose neighbour ORDER also agrees can be compared edge-by-edge
+    for key, got in (("E_head", tr["E"]), ("h_E0_head", tr["h_E0"]), ("hE_final_head", tr["h_E_final"])):
+        for r in range(2):
+            if g["mask"][r] > 0 and np.array_equal(tr["E_idx"][0, r].numpy(), g["E_idx"][r]):
+                np.testing.assert_allclose(got[0, r].numpy(), g[key][r], atol=TOL_INTERMEDIATE, rtol=0)
+    for key in [k for k in g if k.startswith("hV_")]:
+        np.testing.assert_allclose(tr[key][0].numpy(), g[key], atol=TOL_INTERMEDIATE, rtol=0, err_msg=key)
+    np.testing.assert_allclose(tr["log_probs"][0].numpy(), g["log_probs"], atol=TOL_INTERMEDIATE, rtol=0)
+    np.testing.assert_allclose(tr["z"][0].numpy(), g["z"], atol=TOL_INTERMEDIATE, rtol=0)
+    have = ~np.isnan(g["ddg"][:, 0])
+    assert have.sum() == sum(c != "-" for c in str(g["seq"]))
+    np.testing.assert_allclose(ddg[have][:, :20], g["ddg"][have], atol=TOL_DDG, rtol=0)
+    # wild-type -> wild-type is exactly zero (examples/ThermoMPNN_inference_2OCJ.csv property)
+    wt = g["S"].astype(np.int64)
+    sel = have & (wt < 20)
+    assert np.all(ddg[np.nonzero(sel)[0], wt[sel]] == 0.0)
+
+
+def test_reference_shaped_loop_equals_table(synthetic_weights):
+    """The per-mutation loop (transfer_model.py:86-120) and the once-per-position table agree."""
+    from thermompnn_amd.datasets import ALPHABET, Mutation
+    g = load_golden("syn_L32")
+    X, S, mask, chain_M, ridx, cenc = inputs(g)
+    seq = str(g["seq"])
+    muts = [Mutation(p, seq[p], a) for p in (0, 7, 31) for a in ALPHABET[:-1]] + [None]
+    with torch.no_grad():
+        loop = orc.transfer_forward_loop(synthetic_weights, X, S, mask, chain_M, ridx, cenc, muts, ALPHABET)
+        table = orc.ssm_table(synthetic_weights, X, S, mask, chain_M, ridx, cenc)[0]
+    assert loop[-1] is None
+    for m, v in zip(muts[:-1], loop[:-1]):
+        assert abs(float(v) - float(table[m.position, ALPHABET.index(m.mutation)])) <= 2e-6
+        assert abs(float(v) - g["ddg"][m.position, ALPHABET.index(m.mutation)]) <= TOL_DDG
+
+
+def test_gap_case_properties():
+    g = load_golden("2OCJ_A_gap")
+    seq = str(g["seq"])
+    gaps = [i for i, c in enumerate(seq) if c == "-"]
+    assert len(gaps) == 3 and np.all(g["mask"][gaps] == 0) and np.all(g["S"][gaps] == 20)
+    missing_atom = [i for i in np.nonzero(g["mask"] == 0)[0] if i not in gaps]
+    assert len(missing_atom) == 1 and seq[missing_atom[0]] != "-"
+    assert np.all(np.isnan(g["ddg"][gaps])) and not np.any(np.isnan(g["ddg"][missing_atom]))
+    assert np.all(g["hV_dec3"][g["mask"] == 0] == 0.0)       # masked rows are exactly zero
+    # a masked residue appears in no valid row's neighbour list
+    valid_rows = g["E_idx"][g["mask"] > 0]
+    assert not np.isin(valid_rows, np.nonzero(g["mask"] == 0)[0]).any()

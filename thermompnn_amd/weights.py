@@ -1,0 +1,154 @@
+"""Weight formats of the ThermoMPNN hot path: names/shapes, a deterministic synthetic generator,
+and loaders for the two on-disk formats the reference reads.
+
+Reference formats:
+  * vanilla ProteinMPNN: ``torch.load`` -> ``{'num_edges': int, 'model_state_dict': {...}}``
+    (/root/reference/transfer_model.py:25-29)
+  * ThermoMPNN Lightning checkpoint: ``ckpt['state_dict']`` with ``model.`` prefix
+    (/root/reference/analysis/thermompnn_benchmarking.py:78-84, train_thermompnn.py:28-40)
+
+The real checkpoints are not shipped with the reference mount, so parity is pinned with the synthetic
+weights produced here (same generator on the build box and on the GPU box: numpy PCG64 is
+platform-deterministic).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+H = 128          # hidden / node / edge width (transfer_model.py:19)
+VOCAB = 21       # protein_mpnn_utils.py:1186
+N_POS = 16       # num_positional_embeddings (protein_mpnn_utils.py:1085)
+N_RBF = 16
+EDGE_IN = N_POS + 25 * N_RBF   # 416 (protein_mpnn_utils.py:1097)
+HEAD_IN = 3 * H  # num_final_layers(2)*128 + 128 (transfer_model.py:57)
+
+
+def mpnn_param_shapes(num_enc: int = 3, num_dec: int = 3) -> "OrderedDict[str, tuple]":
+    """Names and shapes of ProteinMPNN's state dict, in module-registration order
+    (protein_mpnn_utils.py:1184-1215)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["features.embeddings.linear.weight"] = (N_POS, 66)
+    s["features.embeddings.linear.bias"] = (N_POS,)
+    s["features.edge_embedding.weight"] = (H, EDGE_IN)
+    s["features.norm_edges.weight"] = (H,)
+    s["features.norm_edges.bias"] = (H,)
+    s["W_e.weight"] = (H, H)
+    s["W_e.bias"] = (H,)
+    s["W_s.weight"] = (VOCAB, H)
+
+    def layer(prefix: str, num_in: int, edge_update: bool):
+        norms = ("norm1", "norm2", "norm3") if edge_update else ("norm1", "norm2")
+        for n in norms:
+            s[f"{prefix}.{n}.weight"] = (H,)
+            s[f"{prefix}.{n}.bias"] = (H,)
+        lin = [("W1", H + num_in), ("W2", H), ("W3", H)]
+        if edge_update:
+            lin += [("W11", H + num_in), ("W12", H), ("W13", H)]
+        for n, fan_in in lin:
+            s[f"{prefix}.{n}.weight"] = (H, fan_in)
+            s[f"{prefix}.{n}.bias"] = (H,)
+        s[f"{prefix}.dense.W_in.weight"] = (4 * H, H)
+        s[f"{prefix}.dense.W_in.bias"] = (4 * H,)
+        s[f"{prefix}.dense.W_out.weight"] = (H, 4 * H)
+        s[f"{prefix}.dense.W_out.bias"] = (H,)
+
+    for i in range(num_enc):
+        layer(f"encoder_layers.{i}", 2 * H, True)
+    for i in range(num_dec):
+        layer(f"decoder_layers.{i}", 3 * H, False)
+    s["W_out.weight"] = (VOCAB, H)
+    s["W_out.bias"] = (VOCAB,)
+    return s
+
+
+def head_param_shapes(hidden_dims=(64, 32)) -> "OrderedDict[str, tuple]":
+    """TransferModel's own parameters (transfer_model.py:57-73, 131-134)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    for conv in ("feature_convolution", "attention_convolution"):
+        s[f"light_attention.{conv}.weight"] = (HEAD_IN, HEAD_IN, 9)
+        s[f"light_attention.{conv}.bias"] = (HEAD_IN,)
+    sizes = [HEAD_IN, *hidden_dims, VOCAB]
+    for i, (a, b) in enumerate(zip(sizes, sizes[1:])):
+        s[f"both_out.{2 * i + 1}.weight"] = (b, a)   # ReLU sits at even indices
+        s[f"both_out.{2 * i + 1}.bias"] = (b,)
+    s["ddg_out.weight"] = (1, 1)
+    s["ddg_out.bias"] = (1,)
+    return s
+
+
+def transfer_param_shapes() -> "OrderedDict[str, tuple]":
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    for k, v in mpnn_param_shapes().items():
+        s["prot_mpnn." + k] = v
+    s.update(head_param_shapes())
+    return s
+
+
+def _draw(rng: np.random.Generator, name: str, shape: tuple) -> np.ndarray:
+    leaf = name.rsplit(".", 1)[-1]
+    if name.startswith("ddg_out"):
+        return np.full(shape, 1.7 if leaf == "weight" else -0.3, dtype=np.float32)
+    if ".norm" in name or "norm_edges" in name:
+        if leaf == "weight":
+            return (1.0 + rng.uniform(-0.1, 0.1, shape)).astype(np.float32)
+        return rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+    if leaf == "bias":
+        return rng.normal(0.0, 0.02, shape).astype(np.float32)
+    if len(shape) == 3:                                   # conv taps: all nine non-zero
+        bound = math.sqrt(6.0 / (shape[0] + shape[1]))
+    else:
+        bound = math.sqrt(6.0 / (shape[0] + shape[1]))    # Xavier-uniform (protein_mpnn_utils.py:1217-1219)
+    return rng.uniform(-bound, bound, shape).astype(np.float32)
+
+
+def synthetic_state_dict(seed: int = 0, which: str = "transfer") -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic synthetic weights. ``which`` = 'transfer' (full TransferModel tree) or 'mpnn'."""
+    rng = np.random.default_rng(seed)
+    shapes = transfer_param_shapes() if which == "transfer" else mpnn_param_shapes()
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in shapes.items():
+        out[name] = torch.from_numpy(_draw(rng, name, shape))
+    return out
+
+
+def split_transfer_state_dict(sd):
+    """-> (mpnn_sd without prefix, head_sd)."""
+    mp, hd = OrderedDict(), OrderedDict()
+    for k, v in sd.items():
+        if k.startswith("prot_mpnn."):
+            mp[k[len("prot_mpnn."):]] = v
+        else:
+            hd[k] = v
+    return mp, hd
+
+
+def save_vanilla_checkpoint(path, mpnn_sd, num_edges: int = 48) -> None:
+    torch.save({"num_edges": int(num_edges), "model_state_dict": OrderedDict(mpnn_sd)}, path)
+
+
+def load_vanilla_checkpoint(path):
+    """-> (num_edges, state_dict). Mirrors transfer_model.py:25-29."""
+    ckpt = torch.load(path, map_location="cpu")
+    return int(ckpt["num_edges"]), ckpt["model_state_dict"]
+
+
+def save_lightning_checkpoint(path, transfer_sd) -> None:
+    torch.save({"state_dict": OrderedDict(("model." + k, v) for k, v in transfer_sd.items())}, path)
+
+
+def load_thermompnn_checkpoint(path):
+    """Read a TransferModelPL checkpoint without importing Lightning: strips the ``model.`` prefix
+    (train_thermompnn.py:28-40 registers the TransferModel as ``self.model``)."""
+    try:
+        ckpt = torch.load(path, map_location="cpu")
+    except Exception:  # Lightning checkpoints carry non-tensor hyper-parameter objects
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    out = OrderedDict()
+    for k, v in sd.items():
+        out[k[len("model."):] if k.startswith("model.") else k] = v
+    return out
