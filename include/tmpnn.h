@@ -1,0 +1,152 @@
+/*
+ * tmpnn.h — C-ABI of the MI355X-native ThermoMPNN inference engine (libtmpnn.so).
+ *
+ * Drop-in boundary for the ONE hot path of Kuhlman-Lab/ThermoMPNN:
+ *   tied_featurize tensors -> kNN graph -> edge featurizer -> 3x EncLayer -> 3x DecLayer -> ddG head.
+ * Each entry point names the reference interface it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - extern "C"; every function returns int (0 = TMPNN_OK, negative = error) unless noted;
+ *     no exception crosses the boundary; tmpnn_last_error() returns a thread-local message.
+ *   - All data pointers are BORROWED DEVICE pointers (e.g. torch tensor.data_ptr()); the caller owns
+ *     every buffer including outputs and workspace. The library never allocates device memory and
+ *     never synchronises the stream. `stream` is a hipStream_t passed as void*.
+ *   - Ragged batch layout: proteins are packed along one residue axis of length T = sum(L_p);
+ *     `offsets[N+1]` (int32, device) gives each protein's [start, end). A padded [B, L] batch of the
+ *     reference API is the special case offsets = {0, L, 2L, ...} with mask = 0 on padding.
+ *   - All floating-point data is fp32 (the reference computes in fp32 throughout); indices handed
+ *     across this boundary are int32 except where an entry point mirrors a reference signature that
+ *     takes int64 (gather_nodes / gather_edges).
+ *   - Neighbour slots: every residue owns TMPNN_KS = 48 edge slots; slot k >= min(K, L_p) is
+ *     invalid (E_idx = -1, h_E row = 0). K must be <= 48 (ThermoMPNN uses the v_48_* weights).
+ */
+#ifndef TMPNN_H
+#define TMPNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMPNN_VERSION 100
+#define TMPNN_HID 128          /* hidden width (transfer_model.py:19) */
+#define TMPNN_KS 48            /* neighbour slots per residue */
+#define TMPNN_VOCAB 21
+#define TMPNN_N_MPNN_TENSORS 118
+#define TMPNN_N_TENSORS 130    /* + 12 TransferModel head tensors */
+
+enum {
+    TMPNN_OK = 0,
+    TMPNN_E_INVALID = -1,      /* bad argument (null pointer, negative size, K out of range ...) */
+    TMPNN_E_UNSUPPORTED = -2,  /* valid request outside what this build supports */
+    TMPNN_E_LAUNCH = -3,       /* HIP launch/runtime error (message has hipGetErrorString) */
+    TMPNN_E_WORKSPACE = -4     /* workspace / packed buffer too small */
+};
+
+typedef struct tmpnn_weights tmpnn_weights_t;   /* opaque; immutable after create */
+typedef void *tmpnn_stream_t;                   /* hipStream_t */
+
+int tmpnn_version(void);
+const char *tmpnn_last_error(void);
+
+/* ---- weights ------------------------------------------------------------------------------------
+ * Canonical tensor order = the reference state dict: the 118 ProteinMPNN tensors in module
+ * registration order (protein_mpnn_utils.py:1184-1215), then light_attention.{feature,attention}
+ * _convolution.{weight,bias}, both_out.{1,3,5}.{weight,bias}, ddg_out.{weight,bias}
+ * (transfer_model.py:57-73,131-134). tmpnn_tensor_name(i) spells out entry i so a host can check. */
+int tmpnn_num_tensors(void);
+const char *tmpnn_tensor_name(int index);       /* NULL if out of range */
+int64_t tmpnn_tensor_numel(int index);          /* -1 if out of range */
+
+/* Device bytes the library needs for derived tables (positional table, per-decoder-layer sequence
+ * tables, centre tap of the feature convolution). */
+size_t tmpnn_weights_packed_bytes(void);
+
+/* Replaces: get_protein_mpnn()'s load_state_dict (transfer_model.py:17-37) and the Lightning
+ * checkpoint load (analysis/thermompnn_benchmarking.py:78-84) — the host reads the file, this call
+ * takes the tensors. `tensors[i]` = device pointer to tensor i (fp32, contiguous). n_tensors is 118
+ * (ProteinMPNN only: head calls then fail with TMPNN_E_INVALID) or 130. The raw tensors must stay
+ * alive and unmodified for the handle's lifetime. Derived tables are written into `packed` on
+ * `stream`. */
+int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *tensors, int n_tensors,
+                         void *packed, size_t packed_bytes, tmpnn_stream_t stream);
+void tmpnn_weights_destroy(tmpnn_weights_t *w);
+
+/* ---- graph construction ------------------------------------------------------------------------
+ * Replaces ProteinFeatures._dist + torch.topk (protein_mpnn_utils.py:1101-1109).
+ * X [T,4,3] (N,CA,C,O; NaN already zeroed as tied_featurize does, :577), mask [T].
+ * E_idx [T,48] receives GLOBAL packed row indices sorted by ascending adjusted distance (ties: lower
+ * index first), -1 in invalid slots; D_nb [T,48] the adjusted distances (0 in invalid slots).
+ * max_len = max_p L_p (sizes the per-row LDS scratch; must be <= 8192). */
+int tmpnn_knn_topk(const float *X, const float *mask, const int32_t *offsets, int n_proteins,
+                   int64_t T, int max_len, int K, int32_t *E_idx, float *D_nb, tmpnn_stream_t stream);
+
+/* Replaces ProteinFeatures.forward after top-k (protein_mpnn_utils.py:1140-1180: 25 RBF blocks,
+ * PositionalEncodings :896-908, edge_embedding, norm_edges) fused with W_e (:1229).
+ * residue_idx, chain_enc: int32 [T]. h_E [T,48,128] <- W_e . LN(W_edge . [posenc | RBF]) + b.
+ * E_opt (may be NULL) receives the LayerNorm output E [T,48,128] (what ProteinFeatures returns). */
+int tmpnn_edge_featurize(const tmpnn_weights_t *w, const float *X, const int32_t *residue_idx,
+                         const int32_t *chain_enc, const int32_t *E_idx, const float *D_nb, int64_t T,
+                         float *h_E, float *E_opt, tmpnn_stream_t stream);
+
+/* ---- gathers (the "gather HBM GB/s" kernel of BASELINE.json:metric) ------------------------------
+ * gather_nodes(nodes[B,N,C], neighbor_idx[B,N,K] int64) -> [B,N,K,C]  (protein_mpnn_utils.py:770-778) */
+int tmpnn_gather_nodes(const float *nodes, const int64_t *neighbor_idx, int B, int N, int K, int C,
+                       float *out, tmpnn_stream_t stream);
+/* Same gather on the engine's own layout: out[r,:] = nodes[idx[r],:], idx int32 global rows
+ * (rows with idx < 0 are written as zeros). This is the roofline microbenchmark kernel. */
+int tmpnn_gather_rows_i32(const float *nodes, const int32_t *idx, int64_t n_rows, int C, float *out,
+                          tmpnn_stream_t stream);
+/* gather_edges(edges[B,N,N,C], neighbor_idx[B,N,K] int64) -> [B,N,K,C]  (protein_mpnn_utils.py:763-767) */
+int tmpnn_gather_edges(const float *edges, const int64_t *neighbor_idx, int B, int N, int K, int C,
+                       float *out, tmpnn_stream_t stream);
+
+/* ---- message-passing layers ---------------------------------------------------------------------
+ * Workspace for one layer call / for the fused forward. */
+size_t tmpnn_layer_workspace_bytes(int64_t T);
+size_t tmpnn_workspace_bytes(int64_t T);
+
+/* EncLayer.forward (protein_mpnn_utils.py:816-839) with mask_attend = mask_i*mask_j (:1232-1233).
+ * h_V [T,128] and h_E [T,48,128] are updated in place. */
+int tmpnn_enc_layer(const tmpnn_weights_t *w, int layer, float *h_V, float *h_E, const int32_t *E_idx,
+                    const float *mask, int64_t T, void *workspace, size_t workspace_bytes,
+                    tmpnn_stream_t stream);
+
+/* One decoder step of ProteinMPNN.forward (protein_mpnn_utils.py:1268-1273 + DecLayer.forward
+ * :859-880): h_ESV = mask_i * [h_E | W_s[S_j] | h_V_j], no neighbour mask. h_V_out may alias h_V_in. */
+int tmpnn_dec_layer(const tmpnn_weights_t *w, int layer, const float *h_V_in, float *h_V_out,
+                    const float *h_E, const int32_t *E_idx, const int32_t *S, const float *mask,
+                    int64_t T, void *workspace, size_t workspace_bytes, tmpnn_stream_t stream);
+
+/* h_S = W_s[S] (protein_mpnn_utils.py:1238). */
+int tmpnn_seq_embed(const tmpnn_weights_t *w, const int32_t *S, int64_t T, float *h_S,
+                    tmpnn_stream_t stream);
+/* log_softmax(W_out h_V + b) (protein_mpnn_utils.py:1275-1276) -> [T,21]. */
+int tmpnn_log_probs(const tmpnn_weights_t *w, const float *h_V, int64_t T, float *log_probs,
+                    tmpnn_stream_t stream);
+
+/* ---- ddG head ------------------------------------------------------------------------------------
+ * TransferModel.forward's per-mutation body (transfer_model.py:86-120) evaluated once per POSITION:
+ * x = [hV_last | hV_prev | W_s[S]], y = centre tap of LightAttention's feature conv (:148-155 on a
+ * length-1 sequence), z = both_out(y) (:67-71). ddg [T,21]: ddg[t,a] = (w z_a + b) - (w z_S[t] + b)
+ * (:110-116); z_opt (may be NULL) receives z [T,21]. */
+int tmpnn_ddg_head(const tmpnn_weights_t *w, const float *hV_last, const float *hV_prev,
+                   const int32_t *S, int64_t T, float *ddg, float *z_opt, tmpnn_stream_t stream);
+
+/* ---- the fused path ------------------------------------------------------------------------------
+ * Everything TransferModel.forward does on the device for a ragged batch of N proteins
+ * (transfer_model.py:75-121 + protein_mpnn_utils.py:1222-1277), one call, ~30 launches on `stream`.
+ * Outputs (each may be NULL except ddg): ddg [T,21]; hidden_opt [3,T,128] = decoder states 1..3
+ * (the reference returns them reversed, :1277); log_probs_opt [T,21]; E_idx_opt [T,48] global rows. */
+int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const int32_t *S, const float *mask,
+                      const int32_t *residue_idx, const int32_t *chain_enc, const int32_t *offsets,
+                      int n_proteins, int64_t T, int max_len, int K, float *ddg, float *hidden_opt,
+                      float *log_probs_opt, int32_t *E_idx_opt, void *workspace, size_t workspace_bytes,
+                      tmpnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMPNN_H */

@@ -1,0 +1,68 @@
+"""The C-ABI library loads and exports every symbol include/tmpnn.h declares (no compute calls; CPU only)."""
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "tmpnn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tmpnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from thermompnn_amd import _lib, build
+    build.build_library()
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libtmpnn.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_tensor_table_matches_python_state_dict_order():
+    from thermompnn_amd import _lib, weights
+    lib = _lib.load()
+    shapes = weights.transfer_param_shapes()
+    want = [k[len("prot_mpnn."):] if k.startswith("prot_mpnn.") else k for k in shapes]
+    assert _lib.tensor_names() == want
+    for i, shape in enumerate(shapes.values()):
+        n = 1
+        for s in shape:
+            n *= s
+        assert lib.tmpnn_tensor_numel(i) == n
+    assert lib.tmpnn_tensor_name(130) is None and lib.tmpnn_tensor_numel(-1) == -1
+    assert lib.tmpnn_version() == 100
+    assert lib.tmpnn_workspace_bytes(256) > 256 * 48 * 128 * 4
+    assert lib.tmpnn_weights_packed_bytes() == (66 * 128 + 3 * 21 * 128 + 384 * 384) * 4
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    """Argument validation happens before any launch: bad calls return error codes + a message."""
+    from thermompnn_amd import _lib
+    lib = _lib.load()
+    rc = lib.tmpnn_knn_topk(None, None, None, 1, 10, 10, 48, None, None, None)
+    assert rc == -1 and b"null" in lib.tmpnn_last_error()
+    rc = lib.tmpnn_gather_nodes(None, None, 1, -3, 2, 4, None, None)
+    assert rc == -1 and b"bad shape" in lib.tmpnn_last_error()
+    assert lib.tmpnn_gather_nodes(None, None, 0, 5, 2, 4, None, None) == 0     # empty input is OK
+    with pytest.raises(_lib.TmpnnError):
+        _lib.check(-2, "demo")
+    with pytest.raises(_lib.TmpnnError, match="not found"):
+        _lib.load("/nonexistent/libtmpnn.so")
+
+
+def test_product_refuses_cpu():
+    import torch
+    from thermompnn_amd.engine import Engine, gather_nodes
+    from thermompnn_amd._lib import TmpnnError
+    from thermompnn_amd.weights import synthetic_state_dict
+    with pytest.raises(TmpnnError, match="CUDA"):
+        Engine(synthetic_state_dict(0, "mpnn"), "cpu")
+    with pytest.raises(TmpnnError, match="no CPU path"):
+        gather_nodes(torch.zeros(1, 4, 8), torch.zeros(1, 4, 2, dtype=torch.long))

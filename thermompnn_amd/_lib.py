@@ -1,0 +1,89 @@
+"""ctypes binding of libtmpnn.so (the C-ABI in include/tmpnn.h). Fails loudly when the HIP library is
+missing or does not export the declared surface — there is no CPU or PyTorch fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtmpnn.so")
+
+OK = 0
+KS = 48
+HID = 128
+VOCAB = 21
+N_MPNN_TENSORS = 118
+N_TENSORS = 130
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/tmpnn.h declaration by declaration
+SIGNATURES = {
+    "tmpnn_version": (_i, []),
+    "tmpnn_last_error": (C.c_char_p, []),
+    "tmpnn_num_tensors": (_i, []),
+    "tmpnn_tensor_name": (C.c_char_p, [_i]),
+    "tmpnn_tensor_numel": (_i64, [_i]),
+    "tmpnn_weights_packed_bytes": (_sz, []),
+    "tmpnn_weights_create": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _p, _sz, _p]),
+    "tmpnn_weights_destroy": (None, [_p]),
+    "tmpnn_knn_topk": (_i, [_p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
+    "tmpnn_edge_featurize": (_i, [_p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),
+    "tmpnn_gather_nodes": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "tmpnn_gather_rows_i32": (_i, [_p, _p, _i64, _i, _p, _p]),
+    "tmpnn_gather_edges": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "tmpnn_layer_workspace_bytes": (_sz, [_i64]),
+    "tmpnn_workspace_bytes": (_sz, [_i64]),
+    "tmpnn_enc_layer": (_i, [_p, _i, _p, _p, _p, _p, _i64, _p, _sz, _p]),
+    "tmpnn_dec_layer": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _sz, _p]),
+    "tmpnn_seq_embed": (_i, [_p, _p, _i64, _p, _p]),
+    "tmpnn_log_probs": (_i, [_p, _p, _i64, _p, _p]),
+    "tmpnn_ddg_head": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p]),
+    "tmpnn_ssm_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+}
+
+
+class TmpnnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """Load libtmpnn.so and bind every declared symbol. Raises TmpnnError if the library is absent
+    (build it with ``python -m thermompnn_amd.build`` / ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise TmpnnError(f"{path} not found: the HIP engine is not built (run `python -m thermompnn_amd.build`); "
+                         "there is no CPU fallback for the product path")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise TmpnnError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise TmpnnError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != OK:
+        msg = load().tmpnn_last_error()
+        raise TmpnnError(f"{what or 'tmpnn call'} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def tensor_names():
+    lib = load()
+    return [lib.tmpnn_tensor_name(i).decode() for i in range(lib.tmpnn_num_tensors())]

@@ -1,0 +1,380 @@
+// C-ABI of libtmpnn.so (declared in include/tmpnn.h): argument checking, the weight handle, workspace
+// carving and the launch sequence of the fused forward. No device allocation, no stream sync.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tmpnn_internal.h"
+
+// ---- errors ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int tm_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int tm_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tm_set_error(TMPNN_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return TMPNN_OK;
+}
+int tm_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+extern "C" int tmpnn_version(void) { return TMPNN_VERSION; }
+extern "C" const char *tmpnn_last_error(void) { return g_err; }
+
+// ---- tensor table ---------------------------------------------------------------------------------
+struct TensorSpec { std::string name; int64_t numel; };
+
+static const std::vector<TensorSpec> &tensor_table() {
+    static std::vector<TensorSpec> t;
+    if (!t.empty()) return t;
+    auto add = [&](const std::string &n, int64_t e) { t.push_back({n, e}); };
+    const int H = TMPNN_HID;
+    add("features.embeddings.linear.weight", 16 * 66);
+    add("features.embeddings.linear.bias", 16);
+    add("features.edge_embedding.weight", H * 416);
+    add("features.norm_edges.weight", H);
+    add("features.norm_edges.bias", H);
+    add("W_e.weight", H * H);
+    add("W_e.bias", H);
+    add("W_s.weight", TMPNN_VOCAB * H);
+    auto layer = [&](const std::string &p, int num_in, bool edge) {
+        const char *norms[3] = {"norm1", "norm2", "norm3"};
+        for (int i = 0; i < (edge ? 3 : 2); ++i) { add(p + "." + norms[i] + ".weight", H); add(p + "." + norms[i] + ".bias", H); }
+        add(p + ".W1.weight", (int64_t)H * (H + num_in)); add(p + ".W1.bias", H);
+        add(p + ".W2.weight", H * H); add(p + ".W2.bias", H);
+        add(p + ".W3.weight", H * H); add(p + ".W3.bias", H);
+        if (edge) {
+            add(p + ".W11.weight", (int64_t)H * (H + num_in)); add(p + ".W11.bias", H);
+            add(p + ".W12.weight", H * H); add(p + ".W12.bias", H);
+            add(p + ".W13.weight", H * H); add(p + ".W13.bias", H);
+        }
+        add(p + ".dense.W_in.weight", 4 * H * H); add(p + ".dense.W_in.bias", 4 * H);
+        add(p + ".dense.W_out.weight", 4 * H * H); add(p + ".dense.W_out.bias", H);
+    };
+    for (int i = 0; i < 3; ++i) layer("encoder_layers." + std::to_string(i), 2 * H, true);
+    for (int i = 0; i < 3; ++i) layer("decoder_layers." + std::to_string(i), 3 * H, false);
+    add("W_out.weight", TMPNN_VOCAB * H);
+    add("W_out.bias", TMPNN_VOCAB);
+    // TransferModel head
+    add("light_attention.feature_convolution.weight", 384 * 384 * 9);
+    add("light_attention.feature_convolution.bias", 384);
+    add("light_attention.attention_convolution.weight", 384 * 384 * 9);
+    add("light_attention.attention_convolution.bias", 384);
+    add("both_out.1.weight", 64 * 384); add("both_out.1.bias", 64);
+    add("both_out.3.weight", 32 * 64); add("both_out.3.bias", 32);
+    add("both_out.5.weight", TMPNN_VOCAB * 32); add("both_out.5.bias", TMPNN_VOCAB);
+    add("ddg_out.weight", 1); add("ddg_out.bias", 1);
+    return t;
+}
+
+extern "C" int tmpnn_num_tensors(void) { return (int)tensor_table().size(); }
+extern "C" const char *tmpnn_tensor_name(int i) {
+    const auto &t = tensor_table();
+    return (i < 0 || i >= (int)t.size()) ? nullptr : t[i].name.c_str();
+}
+extern "C" int64_t tmpnn_tensor_numel(int i) {
+    const auto &t = tensor_table();
+    return (i < 0 || i >= (int)t.size()) ? -1 : t[i].numel;
+}
+
+static const size_t POS_TABLE_FLOATS = 66 * TMPNN_HID, SEQ_TABLE_FLOATS = TMPNN_VOCAB * TMPNN_HID,
+                    CONV_CENTER_FLOATS = 384 * 384;
+extern "C" size_t tmpnn_weights_packed_bytes(void) {
+    return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float);
+}
+
+extern "C" int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *tensors, int n_tensors, void *packed,
+                                    size_t packed_bytes, tmpnn_stream_t stream) {
+    if (!out || !tensors || !packed) return tm_set_error(TMPNN_E_INVALID, "weights_create: null argument");
+    if (tensor_table().size() != TMPNN_N_TENSORS) return tm_set_error(TMPNN_E_INVALID, "internal tensor table size");
+    if (n_tensors != TMPNN_N_MPNN_TENSORS && n_tensors != TMPNN_N_TENSORS)
+        return tm_set_error(TMPNN_E_INVALID, "weights_create: n_tensors must be %d or %d, got %d", TMPNN_N_MPNN_TENSORS,
+                            TMPNN_N_TENSORS, n_tensors);
+    if (packed_bytes < tmpnn_weights_packed_bytes())
+        return tm_set_error(TMPNN_E_WORKSPACE, "weights_create: packed buffer %zu < %zu bytes", packed_bytes,
+                            tmpnn_weights_packed_bytes());
+    if (((uintptr_t)packed & 15) != 0) return tm_set_error(TMPNN_E_INVALID, "weights_create: packed buffer must be 16-byte aligned");
+    for (int i = 0; i < n_tensors; ++i)
+        if (!tensors[i] || ((uintptr_t)tensors[i] & 15) != 0)
+            return tm_set_error(TMPNN_E_INVALID, "weights_create: tensor %d (%s) is null or not 16-byte aligned", i,
+                                tmpnn_tensor_name(i));
+    tmpnn_weights *w = new (std::nothrow) tmpnn_weights();
+    if (!w) return tm_set_error(TMPNN_E_INVALID, "weights_create: host allocation failed");
+    memset(w, 0, sizeof(*w));
+    w->n_tensors = n_tensors;
+    std::map<std::string, const float *> by_name;
+    for (int i = 0; i < n_tensors; ++i) { w->t[i] = tensors[i]; by_name[tensor_table()[i].name] = tensors[i]; }
+    auto get = [&](const std::string &n) -> const float * {
+        auto it = by_name.find(n);
+        return it == by_name.end() ? nullptr : it->second;
+    };
+    w->pos_w = get("features.embeddings.linear.weight");
+    w->pos_b = get("features.embeddings.linear.bias");
+    w->edge_w = get("features.edge_embedding.weight");
+    w->norm_edges_w = get("features.norm_edges.weight");
+    w->norm_edges_b = get("features.norm_edges.bias");
+    w->We_w = get("W_e.weight");
+    w->We_b = get("W_e.bias");
+    w->Ws_w = get("W_s.weight");
+    for (int l = 0; l < 3; ++l) {
+        const std::string p = "encoder_layers." + std::to_string(l) + ".";
+        EncW &e = w->enc[l];
+        e.norm1_w = get(p + "norm1.weight"); e.norm1_b = get(p + "norm1.bias");
+        e.norm2_w = get(p + "norm2.weight"); e.norm2_b = get(p + "norm2.bias");
+        e.norm3_w = get(p + "norm3.weight"); e.norm3_b = get(p + "norm3.bias");
+        e.W1 = get(p + "W1.weight"); e.b1 = get(p + "W1.bias");
+        e.W2 = get(p + "W2.weight"); e.b2 = get(p + "W2.bias");
+        e.W3 = get(p + "W3.weight"); e.b3 = get(p + "W3.bias");
+        e.W11 = get(p + "W11.weight"); e.b11 = get(p + "W11.bias");
+        e.W12 = get(p + "W12.weight"); e.b12 = get(p + "W12.bias");
+        e.W13 = get(p + "W13.weight"); e.b13 = get(p + "W13.bias");
+        e.Win = get(p + "dense.W_in.weight"); e.bin = get(p + "dense.W_in.bias");
+        e.Wout = get(p + "dense.W_out.weight"); e.bout = get(p + "dense.W_out.bias");
+        const std::string d = "decoder_layers." + std::to_string(l) + ".";
+        DecW &c = w->dec[l];
+        c.norm1_w = get(d + "norm1.weight"); c.norm1_b = get(d + "norm1.bias");
+        c.norm2_w = get(d + "norm2.weight"); c.norm2_b = get(d + "norm2.bias");
+        c.W1 = get(d + "W1.weight"); c.b1 = get(d + "W1.bias");
+        c.W2 = get(d + "W2.weight"); c.b2 = get(d + "W2.bias");
+        c.W3 = get(d + "W3.weight"); c.b3 = get(d + "W3.bias");
+        c.Win = get(d + "dense.W_in.weight"); c.bin = get(d + "dense.W_in.bias");
+        c.Wout = get(d + "dense.W_out.weight"); c.bout = get(d + "dense.W_out.bias");
+    }
+    w->Wout_w = get("W_out.weight");
+    w->Wout_b = get("W_out.bias");
+    if (n_tensors == TMPNN_N_TENSORS) {
+        w->conv_w = get("light_attention.feature_convolution.weight");
+        w->conv_b = get("light_attention.feature_convolution.bias");
+        const char *idx[3] = {"1", "3", "5"};
+        for (int i = 0; i < 3; ++i) {
+            w->mlp_w[i] = get(std::string("both_out.") + idx[i] + ".weight");
+            w->mlp_b[i] = get(std::string("both_out.") + idx[i] + ".bias");
+        }
+        w->ddg_w = get("ddg_out.weight");
+        w->ddg_b = get("ddg_out.bias");
+    }
+    float *p = (float *)packed;
+    w->pos_table = p; p += POS_TABLE_FLOATS;
+    for (int l = 0; l < 3; ++l) { w->seq_table[l] = p; p += SEQ_TABLE_FLOATS; }
+    w->conv_center = p;
+    int rc = launch_prep_tables(w, (hipStream_t)stream);
+    if (rc != TMPNN_OK) { delete w; return rc; }
+    *out = w;
+    return TMPNN_OK;
+}
+
+extern "C" void tmpnn_weights_destroy(tmpnn_weights_t *w) { delete w; }
+
+// ---- helpers --------------------------------------------------------------------------------------
+#define REQUIRE(cond, ...) do { if (!(cond)) return tm_set_error(TMPNN_E_INVALID, __VA_ARGS__); } while (0)
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != TMPNN_OK) return rc_; } while (0)
+
+static const int64_t T_MAX = ((int64_t)1 << 31) / (TMPNN_KS * 4) - 1;   // int32 tile arithmetic inside kernels
+
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct Carver {
+    char *p; size_t left;
+    void *take(size_t bytes) {
+        bytes = align256(bytes);
+        if (bytes > left) return nullptr;
+        void *r = p; p += bytes; left -= bytes;
+        return r;
+    }
+};
+
+extern "C" size_t tmpnn_layer_workspace_bytes(int64_t T) {
+    if (T < 0) return 0;
+    return align256((size_t)T * 256 * 4) + align256((size_t)T * TMPNN_HID * 4) + align256((size_t)T * 4) + 256;
+}
+extern "C" size_t tmpnn_workspace_bytes(int64_t T) {
+    if (T < 0) return 0;
+    return tmpnn_layer_workspace_bytes(T) + 2 * align256((size_t)T * TMPNN_KS * 4) +
+           align256((size_t)T * TMPNN_KS * TMPNN_HID * 4) + 4 * align256((size_t)T * TMPNN_HID * 4) + 256;
+}
+
+static int carve_layer_ws(void *workspace, size_t bytes, int64_t T, LayerWs *ws, Carver *rest = nullptr) {
+    uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    size_t skip = base - (uintptr_t)workspace;
+    if (!workspace || skip > bytes) return tm_set_error(TMPNN_E_WORKSPACE, "workspace missing or too small");
+    Carver c{(char *)base, bytes - skip};
+    ws->P = (float *)c.take((size_t)T * 256 * 4);
+    ws->Ssum = (float *)c.take((size_t)T * TMPNN_HID * 4);
+    ws->cnt = (float *)c.take((size_t)T * 4);
+    if (!ws->P || !ws->Ssum || !ws->cnt) return tm_set_error(TMPNN_E_WORKSPACE, "workspace too small for T=%lld", (long long)T);
+    if (rest) *rest = c;
+    return TMPNN_OK;
+}
+
+static int run_enc_layer(const tmpnn_weights *w, int l, float *hV, float *hE, const int32_t *E_idx, const float *mask,
+                         int64_t T, const LayerWs &ws, hipStream_t st) {
+    const EncW &e = w->enc[l];
+    // message + node update (EncLayer :819-832)
+    TRY(launch_node_proj(hV, e.W1, 384, e.b1, e.W1 + 256, 384, T, ws.P, st));
+    TRY(launch_msg(false, e.W1 + 128, 384, e.W2, e.b2, ws.P, nullptr, nullptr, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
+    TRY(launch_node_update(e.W3, e.b3, e.norm1_w, e.norm1_b, e.Win, e.bin, e.Wout, e.bout, e.norm2_w, e.norm2_b, hV,
+                           ws.Ssum, ws.cnt, mask, T, hV, st));
+    // edge update with the NEW node states (:834-838)
+    TRY(launch_node_proj(hV, e.W11, 384, e.b11, e.W11 + 256, 384, T, ws.P, st));
+    TRY(launch_enc_edge(e, ws.P, hE, E_idx, T, st));
+    return TMPNN_OK;
+}
+
+static int run_dec_layer(const tmpnn_weights *w, int l, const float *hV_in, float *hV_out, const float *hE,
+                         const int32_t *E_idx, const int32_t *S, const float *mask, int64_t T, const LayerWs &ws,
+                         hipStream_t st) {
+    const DecW &d = w->dec[l];
+    // W1 columns: [0:128) h_i | [128:256) e_ij | [256:384) W_s[S_j] (folded into seq_table) | [384:512) h_j
+    TRY(launch_node_proj(hV_in, d.W1, 512, d.b1, d.W1 + 384, 512, T, ws.P, st));
+    TRY(launch_msg(true, d.W1 + 128, 512, d.W2, d.b2, ws.P, w->seq_table[l], S, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
+    TRY(launch_node_update(d.W3, d.b3, d.norm1_w, d.norm1_b, d.Win, d.bin, d.Wout, d.bout, d.norm2_w, d.norm2_b, hV_in,
+                           ws.Ssum, ws.cnt, mask, T, hV_out, st));
+    return TMPNN_OK;
+}
+
+// ---- entry points ---------------------------------------------------------------------------------
+extern "C" int tmpnn_knn_topk(const float *X, const float *mask, const int32_t *offsets, int n_proteins, int64_t T,
+                              int max_len, int K, int32_t *E_idx, float *D_nb, tmpnn_stream_t stream) {
+    REQUIRE(X && mask && offsets && E_idx && D_nb, "knn_topk: null pointer");
+    REQUIRE(n_proteins >= 0 && T >= 0 && T <= T_MAX, "knn_topk: bad sizes (N=%d, T=%lld)", n_proteins, (long long)T);
+    REQUIRE(K >= 1 && K <= TMPNN_KS, "knn_topk: K=%d outside [1, %d]", K, TMPNN_KS);
+    if (T == 0 || n_proteins == 0) return TMPNN_OK;
+    REQUIRE(max_len >= 1, "knn_topk: max_len must be >= 1");
+    if (max_len > 8192) return tm_set_error(TMPNN_E_UNSUPPORTED, "knn_topk: max_len %d > 8192", max_len);
+    return launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, (hipStream_t)stream);
+}
+
+extern "C" int tmpnn_edge_featurize(const tmpnn_weights_t *w, const float *X, const int32_t *residue_idx,
+                                    const int32_t *chain_enc, const int32_t *E_idx, const float *D_nb, int64_t T,
+                                    float *h_E, float *E_opt, tmpnn_stream_t stream) {
+    REQUIRE(w && X && residue_idx && chain_enc && E_idx && D_nb && h_E, "edge_featurize: null pointer");
+    REQUIRE(T >= 0 && T <= T_MAX, "edge_featurize: bad T");
+    if (T == 0) return TMPNN_OK;
+    return launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, h_E, E_opt, (hipStream_t)stream);
+}
+
+extern "C" int tmpnn_gather_nodes(const float *nodes, const int64_t *neighbor_idx, int B, int N, int K, int C, float *out,
+                                  tmpnn_stream_t stream) {
+    REQUIRE(B >= 0 && N >= 0 && K >= 0 && C >= 1, "gather_nodes: bad shape");
+    if ((int64_t)B * N * K == 0) return TMPNN_OK;
+    REQUIRE(nodes && neighbor_idx && out, "gather_nodes: null pointer");
+    return launch_gather_rows(nodes, neighbor_idx, 1, (int64_t)B * N * K, (int64_t)N * K, N, C, out, (hipStream_t)stream);
+}
+
+extern "C" int tmpnn_gather_rows_i32(const float *nodes, const int32_t *idx, int64_t n_rows, int C, float *out,
+                                     tmpnn_stream_t stream) {
+    REQUIRE(n_rows >= 0 && C >= 1, "gather_rows_i32: bad shape");
+    if (n_rows == 0) return TMPNN_OK;
+    REQUIRE(nodes && idx && out, "gather_rows_i32: null pointer");
+    return launch_gather_rows(nodes, idx, 0, n_rows, 0, 0, C, out, (hipStream_t)stream);
+}
+
+extern "C" int tmpnn_gather_edges(const float *edges, const int64_t *neighbor_idx, int B, int N, int K, int C, float *out,
+                                  tmpnn_stream_t stream) {
+    REQUIRE(B >= 0 && N >= 0 && K >= 0 && C >= 1, "gather_edges: bad shape");
+    if ((int64_t)B * N * K == 0) return TMPNN_OK;
+    REQUIRE(edges && neighbor_idx && out, "gather_edges: null pointer");
+    return launch_gather_edges(edges, neighbor_idx, B, N, K, C, out, (hipStream_t)stream);
+}
+
+extern "C" int tmpnn_enc_layer(const tmpnn_weights_t *w, int layer, float *h_V, float *h_E, const int32_t *E_idx,
+                               const float *mask, int64_t T, void *workspace, size_t workspace_bytes,
+                               tmpnn_stream_t stream) {
+    REQUIRE(w && h_V && h_E && E_idx && mask, "enc_layer: null pointer");
+    REQUIRE(layer >= 0 && layer < 3, "enc_layer: layer %d outside [0,3)", layer);
+    REQUIRE(T >= 0 && T <= T_MAX, "enc_layer: bad T");
+    if (T == 0) return TMPNN_OK;
+    LayerWs ws;
+    TRY(carve_layer_ws(workspace, workspace_bytes, T, &ws));
+    return run_enc_layer(w, layer, h_V, h_E, E_idx, mask, T, ws, (hipStream_t)stream);
+}
+
+extern "C" int tmpnn_dec_layer(const tmpnn_weights_t *w, int layer, const float *h_V_in, float *h_V_out, const float *h_E,
+                               const int32_t *E_idx, const int32_t *S, const float *mask, int64_t T, void *workspace,
+                               size_t workspace_bytes, tmpnn_stream_t stream) {
+    REQUIRE(w && h_V_in && h_V_out && h_E && E_idx && S && mask, "dec_layer: null pointer");
+    REQUIRE(layer >= 0 && layer < 3, "dec_layer: layer %d outside [0,3)", layer);
+    REQUIRE(T >= 0 && T <= T_MAX, "dec_layer: bad T");
+    if (T == 0) return TMPNN_OK;
+    LayerWs ws;
+    TRY(carve_layer_ws(workspace, workspace_bytes, T, &ws));
+    return run_dec_layer(w, layer, h_V_in, h_V_out, h_E, E_idx, S, mask, T, ws, (hipStream_t)stream);
+}
+
+extern "C" int tmpnn_seq_embed(const tmpnn_weights_t *w, const int32_t *S, int64_t T, float *h_S, tmpnn_stream_t stream) {
+    REQUIRE(w && S && h_S && T >= 0, "seq_embed: bad argument");
+    if (T == 0) return TMPNN_OK;
+    return launch_seq_embed(w, S, T, h_S, (hipStream_t)stream);
+}
+
+extern "C" int tmpnn_log_probs(const tmpnn_weights_t *w, const float *h_V, int64_t T, float *log_probs,
+                               tmpnn_stream_t stream) {
+    REQUIRE(w && h_V && log_probs && T >= 0 && T <= T_MAX, "log_probs: bad argument");
+    if (T == 0) return TMPNN_OK;
+    return launch_log_probs(w, h_V, T, log_probs, (hipStream_t)stream);
+}
+
+extern "C" int tmpnn_ddg_head(const tmpnn_weights_t *w, const float *hV_last, const float *hV_prev, const int32_t *S,
+                              int64_t T, float *ddg, float *z_opt, tmpnn_stream_t stream) {
+    REQUIRE(w && hV_last && hV_prev && S && ddg && T >= 0 && T <= T_MAX, "ddg_head: bad argument");
+    REQUIRE(w->n_tensors == TMPNN_N_TENSORS, "ddg_head: weight handle was created without the TransferModel head tensors");
+    if (T == 0) return TMPNN_OK;
+    return launch_head(w, hV_last, hV_prev, S, T, ddg, z_opt, (hipStream_t)stream);
+}
+
+extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const int32_t *S, const float *mask,
+                                 const int32_t *residue_idx, const int32_t *chain_enc, const int32_t *offsets,
+                                 int n_proteins, int64_t T, int max_len, int K, float *ddg, float *hidden_opt,
+                                 float *log_probs_opt, int32_t *E_idx_opt, void *workspace, size_t workspace_bytes,
+                                 tmpnn_stream_t stream) {
+    REQUIRE(w && X && S && mask && residue_idx && chain_enc && offsets, "ssm_forward: null input pointer");
+    REQUIRE(ddg || hidden_opt || log_probs_opt, "ssm_forward: no output requested");
+    REQUIRE(!ddg || w->n_tensors == TMPNN_N_TENSORS, "ssm_forward: ddg requested but the handle has no head tensors");
+    REQUIRE(n_proteins >= 0 && T >= 0 && T <= T_MAX, "ssm_forward: bad sizes");
+    REQUIRE(K >= 1 && K <= TMPNN_KS, "ssm_forward: K=%d outside [1, %d]", K, TMPNN_KS);
+    if (T == 0 || n_proteins == 0) return TMPNN_OK;
+    if (max_len > 8192) return tm_set_error(TMPNN_E_UNSUPPORTED, "ssm_forward: max_len %d > 8192", max_len);
+    hipStream_t st = (hipStream_t)stream;
+
+    LayerWs ws;
+    Carver c{nullptr, 0};
+    TRY(carve_layer_ws(workspace, workspace_bytes, T, &ws, &c));
+    int32_t *E_idx = (int32_t *)c.take((size_t)T * TMPNN_KS * 4);
+    float *D_nb = (float *)c.take((size_t)T * TMPNN_KS * 4);
+    float *hE = (float *)c.take((size_t)T * TMPNN_KS * TMPNN_HID * 4);
+    float *hV[4];
+    for (int i = 0; i < 4; ++i) hV[i] = (float *)c.take((size_t)T * TMPNN_HID * 4);
+    if (!E_idx || !D_nb || !hE || !hV[3])
+        return tm_set_error(TMPNN_E_WORKSPACE, "ssm_forward: workspace %zu < %zu bytes", workspace_bytes, tmpnn_workspace_bytes(T));
+    if (E_idx_opt) E_idx = E_idx_opt;
+    if (hidden_opt) for (int l = 0; l < 3; ++l) hV[1 + l] = hidden_opt + (size_t)l * T * TMPNN_HID;
+
+    TRY(launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, st));
+    TRY(launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, hE, nullptr, st));
+    if (hipMemsetAsync(hV[0], 0, (size_t)T * TMPNN_HID * 4, st) != hipSuccess)          // h_V starts at zero (:1228)
+        return tm_set_error(TMPNN_E_LAUNCH, "ssm_forward: memset failed");
+    for (int l = 0; l < 3; ++l) TRY(run_enc_layer(w, l, hV[0], hE, E_idx, mask, T, ws, st));
+    for (int l = 0; l < 3; ++l) TRY(run_dec_layer(w, l, hV[l], hV[l + 1], hE, E_idx, S, mask, T, ws, st));
+    if (ddg) TRY(launch_head(w, hV[3], hV[2], S, T, ddg, nullptr, st));
+    if (log_probs_opt) TRY(launch_log_probs(w, hV[3], T, log_probs_opt, st));
+    return TMPNN_OK;
+}

@@ -1,0 +1,103 @@
+// Device-side building blocks shared by the ThermoMPNN kernels (gfx950 / CDNA4 only).
+//
+// Tile convention: every per-edge / per-node GEMM works on a TILE of 48 rows x 128 fp32 features held
+// in LDS (one residue's 48 neighbour slots, or 48 residues). A 256-thread workgroup = 4 wavefronts;
+// wavefront w owns output columns [32w, 32w+32) as two 16-column blocks and keeps the matching slice
+// of the weight matrix in VGPRs. The matrix core instruction is v_mfma_f32_16x16x4_f32 (exact fp32
+// FMA chains), used "transposed": the WEIGHT slice is the MFMA A operand (i = output column), the
+// ACTIVATION tile is the B operand (j = row), so lane (j = lane&15, q = lane>>4) ends up holding four
+// CONSECUTIVE output columns 4q..4q+3 of row j — one 16-byte LDS/global access per 16x16 block.
+//
+// LDS tiles are row-major with an XOR swizzle on the 16-byte chunk index (chunk ^ (row & 15)): the
+// ds_read_b128 of a B fragment (16 rows x same chunk) and the ds_write_b128 of the epilogue are both
+// bank-conflict free (MI355X_MICROARCH.md §LDS lane groups).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TM_H 128
+#define TM_KS 48
+#define TM_TILE 48
+#define TM_THREADS 256
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// float offset of 16-byte chunk `c` of row `m` in a swizzled tile whose rows are RS floats long
+template <int RS = 128>
+__device__ __forceinline__ int chunk_off(int m, int c) { return m * RS + ((c ^ (m & 15)) << 2); }
+
+__device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+
+// exact-erf GELU (torch.nn.GELU() default; protein_mpnn_utils.py:813,856,888)
+__device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ f4 gelu4(f4 v) { return f4{gelu1(v.x), gelu1(v.y), gelu1(v.z), gelu1(v.w)}; }
+
+// Weight fragment for one 16-column block: wr[4*kk+s] = W[(n0 + lane&15) * ld + k0 + 16*kk + 4*(lane>>4) + s].
+// Rows >= n_rows (ragged last block, e.g. 21 logits) read as zero.
+template <int NK16>
+__device__ __forceinline__ void load_wfrag(const float *__restrict__ W, int ld, int n0, int k0, int n_rows,
+                                           float (&wr)[NK16 * 4], int lane) {
+    const int row = n0 + (lane & 15);
+    const float *p = W + (size_t)row * ld + k0 + 4 * (lane >> 4);
+    const bool ok = row < n_rows;
+#pragma unroll
+    for (int kk = 0; kk < NK16; ++kk) {
+        f4 v = ok ? ld4(p + 16 * kk) : f4{0.f, 0.f, 0.f, 0.f};
+        wr[4 * kk + 0] = v.x; wr[4 * kk + 1] = v.y; wr[4 * kk + 2] = v.z; wr[4 * kk + 3] = v.w;
+    }
+}
+
+// acc[rb][cb] += W_cb . tile^T over K = 16*NK16, for the 3 row blocks of a 48-row tile.
+template <int NK16, int NCB, int RS = 128>
+__device__ __forceinline__ void mma_tile(const float *tile, const float (&w)[NCB][NK16 * 4],
+                                         f4 (&acc)[3][NCB], int lane) {
+    const int m = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < NK16; ++kk) {
+        f4 a[3];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) a[rb] = ld4(tile + chunk_off<RS>(16 * rb + m, 4 * kk + q));
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma16(w[cb][4 * kk + s], a[rb][s], acc[rb][cb]);
+    }
+}
+
+// Cooperative load of a contiguous [48,128] fp32 block from global into a swizzled LDS tile
+// (coalesced 16-byte loads; 6 per thread). rows_valid < 48 zero-fills the tail rows.
+__device__ __forceinline__ void load_tile(float *tile, const float *__restrict__ src, int rows_valid, int tid) {
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int idx = it * TM_THREADS + tid;
+        const int row = idx >> 5, c = idx & 31;
+        f4 v = row < rows_valid ? ld4(src + (size_t)idx * 4) : f4{0.f, 0.f, 0.f, 0.f};
+        st4(tile + chunk_off(row, c), v);
+    }
+}
+
+__device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 lanes of a half-wavefront
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+// LayerNorm of one 128-wide row held as one f4 per lane of a half-wavefront (nn.LayerNorm, eps 1e-5,
+// biased variance). g4/b4 = this lane's 4 gamma/beta values.
+__device__ __forceinline__ f4 layer_norm_row(f4 v, f4 g4, f4 b4) {
+    const float mean = half_wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 128.0f);
+    const f4 d = v - mean;
+    const float var = half_wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / 128.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    return d * rstd * g4 + b4;
+}

@@ -1,0 +1,360 @@
+// k-NN graph construction, the fused edge featurizer and the standalone gathers (gfx950).
+//
+// Reference semantics: ProteinFeatures (/root/reference/protein_mpnn_utils.py:1084-1180),
+// PositionalEncodings (:896-908), gather_edges (:763-767), gather_nodes (:770-778).
+// Nothing here materialises an L x L matrix: distances are computed per row (kNN) or per edge (RBF).
+#include "tmpnn_common.h"
+#include "tmpnn_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// knn_topk: one wavefront per residue row. The row's adjusted distances live in LDS; selection is
+// K rounds of a wavefront-wide 64-bit (distance bits, index) min with per-lane cached minima.
+//   D = m_i m_j sqrt(|Ca_i - Ca_j|^2 + 1e-6);  D_adj = D + (1 - m_i m_j) max_j D      (:1101-1106)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+__global__ __launch_bounds__(TM_THREADS) void knn_kernel(const float *__restrict__ X, const float *__restrict__ mask,
+                                                         const int32_t *__restrict__ offsets, int N, int T, int max_len,
+                                                         int K, int32_t *__restrict__ E_idx, float *__restrict__ D_nb) {
+    extern __shared__ __attribute__((aligned(16))) float knn_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *d = knn_lds + (size_t)wv * max_len;
+    const unsigned long long KEY_INF = ~0ull;
+
+    for (int i = blockIdx.x * 4 + wv; i < T; i += gridDim.x * 4) {
+        int lo = 0, hi = N;                      // protein p with offsets[p] <= i < offsets[p+1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (offsets[mid] <= i) lo = mid; else hi = mid;
+        }
+        const int s = offsets[lo], L = offsets[lo + 1] - s;
+        const int Keff = K < L ? K : L;
+        const float xi = X[(size_t)i * 12 + 3], yi = X[(size_t)i * 12 + 4], zi = X[(size_t)i * 12 + 5];
+        const float mi = mask[i];
+
+        float dmax = 0.f;
+        for (int j = lane; j < L; j += 64) {
+            const float *c = X + (size_t)(s + j) * 12 + 3;
+            const float dx = c[0] - xi, dy = c[1] - yi, dz = c[2] - zi;
+            const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            const float D = __fmul_rn(mi * mask[s + j], __fsqrt_rn(__fadd_rn(s2, 1e-6f)));
+            d[j] = D;
+            dmax = fmaxf(dmax, D);
+        }
+        dmax = wave_max_f32(dmax);
+        unsigned long long best = KEY_INF;
+        for (int j = lane; j < L; j += 64) {
+            const float m2 = mi * mask[s + j];
+            const float Da = __fadd_rn(d[j], __fmul_rn(1.0f - m2, dmax));
+            d[j] = Da;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(Da) << 32) | (unsigned)j;
+            best = key < best ? key : best;
+        }
+        wave_lds_fence();
+        for (int t = 0; t < Keff; ++t) {
+            const unsigned long long g = wave_min_u64(best);
+            const int j = (int)(g & 0xffffffffu);
+            if (lane == 0) {
+                E_idx[(size_t)i * TM_KS + t] = s + j;
+                D_nb[(size_t)i * TM_KS + t] = __uint_as_float((unsigned)(g >> 32));
+            }
+            if ((j & 63) == lane) {              // owner lane retires j and rescans its stripe
+                d[j] = __uint_as_float(0x7f800000u);
+                best = KEY_INF;
+                for (int jj = lane; jj < L; jj += 64) {
+                    const unsigned bits = __float_as_uint(d[jj]);
+                    if (bits != 0x7f800000u) {
+                        const unsigned long long key = ((unsigned long long)bits << 32) | (unsigned)jj;
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        }
+        for (int t = Keff + lane; t < TM_KS; t += 64) {
+            E_idx[(size_t)i * TM_KS + t] = -1;
+            D_nb[(size_t)i * TM_KS + t] = 0.f;
+        }
+        wave_lds_fence();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// edge_featurize: one residue (48 edge slots) per workgroup iteration.
+//   25 atom-pair distances -> 400 RBFs in LDS -> [48x400]x[400x128] on the matrix cores (+ folded
+//   positional table) -> LayerNorm -> W_e -> h_E.   W_edge's RBF columns live in VGPRs (200/lane).
+// ------------------------------------------------------------------------------------------------
+#define RBF_RS 448   // padded row length (floats) of the swizzled RBF tile: 100 chunks used of 112
+
+__constant__ int c_pair_a[25] = {1, 0, 2, 3, 4, 1, 1, 1, 1, 0, 0, 0, 4, 4, 3, 0, 2, 3, 4, 2, 3, 4, 2, 3, 2};
+__constant__ int c_pair_b[25] = {1, 0, 2, 3, 4, 0, 2, 3, 4, 2, 3, 4, 2, 3, 2, 1, 1, 1, 1, 0, 0, 0, 4, 4, 3};
+
+struct FeatArgs {
+    const float *edge_w;     // [128,416]
+    const float *pos_table;  // [66,128]
+    const float *ln_w, *ln_b, *We_w, *We_b;
+    const float *X;          // [T,4,3]
+    const int32_t *ridx, *cenc, *E_idx;
+    const float *D_nb;
+    float *hE, *E_opt;
+    int T;
+    float mu[16];            // torch.linspace(2, 22, 16)
+};
+
+__device__ __forceinline__ void atoms5(const float *__restrict__ x, float *out /*[15]*/) {
+    float n[3], ca[3], c[3], o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { n[k] = x[k]; ca[k] = x[3 + k]; c[k] = x[6 + k]; o[k] = x[9 + k]; }
+    float b[3], cc[3], a[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { b[k] = ca[k] - n[k]; cc[k] = c[k] - ca[k]; }
+    a[0] = b[1] * cc[2] - b[2] * cc[1];
+    a[1] = b[2] * cc[0] - b[0] * cc[2];
+    a[2] = b[0] * cc[1] - b[1] * cc[0];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        out[k] = n[k]; out[3 + k] = ca[k]; out[6 + k] = c[k]; out[9 + k] = o[k];
+        out[12 + k] = -0.58273431f * a[k] + 0.56802827f * b[k] - 0.54067466f * cc[k] + ca[k];   // virtual Cb (:1134)
+    }
+}
+
+__global__ __launch_bounds__(TM_THREADS, 1) void featurize_kernel(FeatArgs a) {
+    __shared__ __attribute__((aligned(16))) float rbf[TM_TILE * RBF_RS];
+    __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];
+    __shared__ float s_atoms[TM_TILE][16];
+    __shared__ float s_self[16];
+    __shared__ float s_dist[TM_TILE][28];
+    __shared__ int s_idx[TM_TILE];
+    __shared__ int s_dpos[TM_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int c32 = lane & 31;
+
+    float wedge[2][100], we[2][32];
+    f4 be[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int n0 = 32 * wv + 16 * cb;
+        load_wfrag<25>(a.edge_w, 416, n0, 16, TM_H, wedge[cb], lane);
+        load_wfrag<8>(a.We_w, TM_H, n0, 0, TM_H, we[cb], lane);
+        be[cb] = ld4(a.We_b + n0 + 4 * q);
+    }
+    const f4 g4 = ld4(a.ln_w + 4 * c32), b4 = ld4(a.ln_b + 4 * c32);
+
+    for (int i = blockIdx.x; i < a.T; i += gridDim.x) {
+        if (tid < TM_TILE) {
+            const int j = a.E_idx[(size_t)i * TM_KS + tid];
+            s_idx[tid] = j;
+            const int jj = j < 0 ? i : j;
+            float at[15];
+            atoms5(a.X + (size_t)jj * 12, at);
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s_atoms[tid][k] = at[k];
+            // PositionalEncodings index (:903-905, :1170-1175)
+            const int off = a.ridx[i] - a.ridx[jj];
+            const int same = a.cenc[i] == a.cenc[jj];
+            s_dpos[tid] = same ? min(max(off + 32, 0), 64) : 65;
+        } else if (tid == 64) {
+            float at[15];
+            atoms5(a.X + (size_t)i * 12, at);
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s_self[k] = at[k];
+        }
+        __syncthreads();
+        for (int e = tid; e < TM_TILE * 25; e += TM_THREADS) {
+            const int mm = e / 25, p = e - mm * 25;
+            float D;
+            if (p == 0) {
+                D = a.D_nb[(size_t)i * TM_KS + mm];            // masked Ca-Ca distance from _dist (:1142)
+            } else {
+                const float *A = s_self + 3 * c_pair_a[p];
+                const float *B = s_atoms[mm] + 3 * c_pair_b[p];
+                const float dx = A[0] - B[0], dy = A[1] - B[1], dz = A[2] - B[2];
+                D = sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);  // _get_rbf (:1122)
+            }
+            s_dist[mm][p] = D;
+        }
+        __syncthreads();
+        for (int e = tid; e < TM_TILE * 100; e += TM_THREADS) {   // 16 Gaussians per pair, 4 per thread (:1111-1119)
+            const int mm = e / 100, c = e - mm * 100;
+            const float D = s_dist[mm][c >> 2];
+            const int r0 = (c & 3) * 4;
+            f4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = (D - a.mu[r0 + r]) * 0.8f;         // / sigma, sigma = 1.25
+                v[r] = __expf(-(t * t));
+            }
+            st4(rbf + chunk_off<RBF_RS>(mm, c), v);
+        }
+        __syncthreads();
+
+        f4 acc[3][2];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const float *pt = a.pos_table + s_dpos[16 * rb + m] * TM_H + 32 * wv + 4 * q;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = ld4(pt + 16 * cb);
+        }
+        mma_tile<25, 2, RBF_RS>(rbf, wedge, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) st4(tA + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), acc[rb][cb]);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {                         // norm_edges (:1179)
+            const int row = 12 * wv + 2 * it + (lane >> 5);
+            float *p = tA + chunk_off(row, c32);
+            const f4 y = layer_norm_row(ld4(p), g4, b4);
+            st4(p, y);
+            if (a.E_opt) {
+                const bool ok = s_idx[row] >= 0;
+                st4(a.E_opt + ((size_t)i * TM_KS + row) * TM_H + 4 * c32, ok ? y : f4{0.f, 0.f, 0.f, 0.f});
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = be[cb];
+        mma_tile<8, 2>(tA, we, acc, lane);                        // W_e (:1229)
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) st4(tB + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), acc[rb][cb]);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int row = 12 * wv + 2 * it + (lane >> 5);
+            const f4 y = s_idx[row] >= 0 ? ld4(tB + chunk_off(row, c32)) : f4{0.f, 0.f, 0.f, 0.f};
+            st4(a.hE + ((size_t)i * TM_KS + row) * TM_H + 4 * c32, y);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gathers
+// ------------------------------------------------------------------------------------------------
+// out[r, :] = nodes[base(r) + idx[r], :] with C % 4 == 0; one 16-byte chunk per thread-iteration.
+template <typename IdxT>
+__global__ __launch_bounds__(TM_THREADS) void gather_rows_kernel(const float *__restrict__ nodes,
+                                                                 const IdxT *__restrict__ idx, int64_t n_rows,
+                                                                 int64_t rows_per_batch, int64_t nodes_per_batch,
+                                                                 int C4, float *__restrict__ out) {
+    const int64_t total = n_rows * C4;
+    const int64_t stride = (int64_t)gridDim.x * TM_THREADS;
+    for (int64_t g = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x; g < total; g += stride) {
+        const int64_t r = g / C4;
+        const int c = (int)(g - r * C4);
+        const int64_t j = (int64_t)idx[r];
+        f4 v = f4{0.f, 0.f, 0.f, 0.f};
+        if (j >= 0) {
+            const int64_t base = rows_per_batch > 0 ? (r / rows_per_batch) * nodes_per_batch : 0;
+            v = ld4(nodes + ((base + j) * C4 + c) * 4);
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out) + g);
+    }
+}
+
+// scalar fallback for C % 4 != 0 (e.g. gather_nodes(mask.unsqueeze(-1), E_idx), :1232)
+template <typename IdxT>
+__global__ __launch_bounds__(TM_THREADS) void gather_rows_scalar_kernel(const float *__restrict__ nodes,
+                                                                        const IdxT *__restrict__ idx, int64_t n_rows,
+                                                                        int64_t rows_per_batch, int64_t nodes_per_batch,
+                                                                        int C, float *__restrict__ out) {
+    const int64_t total = n_rows * C;
+    const int64_t stride = (int64_t)gridDim.x * TM_THREADS;
+    for (int64_t g = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x; g < total; g += stride) {
+        const int64_t r = g / C;
+        const int c = (int)(g - r * C);
+        const int64_t j = (int64_t)idx[r];
+        const int64_t base = rows_per_batch > 0 ? (r / rows_per_batch) * nodes_per_batch : 0;
+        out[g] = j >= 0 ? nodes[(base + j) * C + c] : 0.f;
+    }
+}
+
+// out[b,i,k,:] = edges[b,i,idx[b,i,k],:]
+__global__ __launch_bounds__(TM_THREADS) void gather_edges_kernel(const float *__restrict__ edges,
+                                                                  const int64_t *__restrict__ idx, int64_t n_rows,
+                                                                  int N, int K, int C, float *__restrict__ out) {
+    const int64_t total = n_rows * C;
+    const int64_t stride = (int64_t)gridDim.x * TM_THREADS;
+    for (int64_t g = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x; g < total; g += stride) {
+        const int64_t r = g / C;            // r = (b*N + i)*K + k
+        const int c = (int)(g - r * C);
+        const int64_t bi = r / K;
+        out[g] = edges[(bi * N + idx[r]) * C + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,
+               int32_t *E_idx, float *D_nb, hipStream_t st) {
+    const size_t lds = (size_t)4 * max_len * sizeof(float);
+    if (lds > 160 * 1024) return tm_set_error(TMPNN_E_UNSUPPORTED, "knn_topk: max_len %d needs %zu B of LDS", max_len, lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int64_t blocks = (T + 3) / 4;
+    const int64_t cap = (int64_t)tm_num_cus() * 8;
+    knn_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb);
+    return tm_check_launch("knn_topk");
+}
+
+int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx, const int32_t *cenc,
+                     const int32_t *E_idx, const float *D_nb, int64_t T, float *h_E, float *E_opt, hipStream_t st) {
+    FeatArgs a;
+    a.edge_w = w->edge_w; a.pos_table = w->pos_table; a.ln_w = w->norm_edges_w; a.ln_b = w->norm_edges_b;
+    a.We_w = w->We_w; a.We_b = w->We_b; a.X = X; a.ridx = ridx; a.cenc = cenc; a.E_idx = E_idx; a.D_nb = D_nb;
+    a.hE = h_E; a.E_opt = E_opt; a.T = (int)T;
+    for (int i = 0; i < 16; ++i)   // torch.linspace(2, 22, 16): double arithmetic, symmetric halves, cast to fp32
+        a.mu[i] = i < 8 ? (float)(2.0 + (20.0 / 15.0) * i) : (float)(22.0 - (20.0 / 15.0) * (15 - i));
+    const int64_t cap = tm_num_cus();
+    featurize_kernel<<<(int)(T < cap ? T : cap), TM_THREADS, 0, st>>>(a);
+    return tm_check_launch("edge_featurize");
+}
+
+int launch_gather_rows(const float *nodes, const void *idx, int idx64, int64_t n_rows, int64_t rows_per_batch,
+                       int64_t nodes_per_batch, int C, float *out, hipStream_t st) {
+    if (n_rows == 0) return TMPNN_OK;
+    const int64_t cap = (int64_t)tm_num_cus() * 16;
+    if (C % 4 == 0) {
+        const int64_t blocks = (n_rows * (C / 4) + TM_THREADS - 1) / TM_THREADS;
+        const int grid = (int)(blocks < cap ? blocks : cap);
+        if (idx64) gather_rows_kernel<int64_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int64_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C / 4, out);
+        else gather_rows_kernel<int32_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int32_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C / 4, out);
+    } else {
+        const int64_t blocks = (n_rows * C + TM_THREADS - 1) / TM_THREADS;
+        const int grid = (int)(blocks < cap ? blocks : cap);
+        if (idx64) gather_rows_scalar_kernel<int64_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int64_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C, out);
+        else gather_rows_scalar_kernel<int32_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int32_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C, out);
+    }
+    return tm_check_launch("gather_rows");
+}
+
+int launch_gather_edges(const float *edges, const int64_t *idx, int B, int N, int K, int C, float *out, hipStream_t st) {
+    const int64_t n_rows = (int64_t)B * N * K;
+    if (n_rows == 0) return TMPNN_OK;
+    const int64_t blocks = (n_rows * C + TM_THREADS - 1) / TM_THREADS;
+    const int64_t cap = (int64_t)tm_num_cus() * 16;
+    gather_edges_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(edges, idx, n_rows, N, K, C, out);
+    return tm_check_launch("gather_edges");
+}

@@ -1,0 +1,206 @@
+// ddG head, sequence-logit epilogue, sequence embedding and the derived-table preparation (gfx950).
+//
+// Reference semantics: TransferModel.forward (/root/reference/transfer_model.py:86-120) evaluated once
+// per POSITION instead of once per mutation; LightAttention on a length-1 sequence (:148-155) = centre
+// tap of feature_convolution (softmax over a size-1 axis is 1, dropout is identity in eval);
+// both_out = [ReLU, Linear] x3 (:67-71); ddg_out = Linear(1,1) (:73); W_out + log_softmax
+// (protein_mpnn_utils.py:1275-1276); W_s embedding (:1238).
+#include "tmpnn_common.h"
+#include "tmpnn_internal.h"
+
+struct HeadArgs {
+    const float *conv_center, *conv_b;   // [384,384], [384]
+    const float *w1, *b1, *w2, *b2, *w3, *b3;   // 384->64, 64->32, 32->21
+    const float *ddg_w, *ddg_b;
+    const float *Ws;                      // [21,128]
+    const float *hA, *hB;                 // last / previous decoder state [T,128]
+    const int32_t *S;
+    float *ddg, *z_opt;
+    int T;
+};
+
+__device__ __forceinline__ f4 relu4(f4 v) { return f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
+
+__global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
+    __shared__ __attribute__((aligned(16))) float tX[3][TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tY[3][TM_TILE * TM_H];
+    __shared__ int s_S[TM_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int n_tiles = (a.T + TM_TILE - 1) / TM_TILE;
+    const float dw = a.ddg_w[0], db = a.ddg_b[0];
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int r0 = tile * TM_TILE, rows = min(TM_TILE, a.T - r0);
+        if (tid < TM_TILE) s_S[tid] = tid < rows ? a.S[r0 + tid] : 0;
+        load_tile(tX[0], a.hA + (size_t)r0 * TM_H, rows, tid);
+        load_tile(tX[1], a.hB + (size_t)r0 * TM_H, rows, tid);
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {        // x[256:384] = W_s[S]
+            const int idx = it * TM_THREADS + tid, row = idx >> 5, c = idx & 31;
+            const int s = row < rows ? a.S[r0 + row] : 0;
+            st4(tX[2] + chunk_off(row, c), ld4(a.Ws + s * TM_H + 4 * c));
+        }
+        __syncthreads();
+
+        // y = relu(Wc x + bc), 384 -> 384 in three 128-column groups
+        for (int g = 0; g < 3; ++g) {
+            f4 acc[3][2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const f4 b = ld4(a.conv_b + 128 * g + 32 * wv + 16 * cb + 4 * q);
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = b;
+            }
+            for (int kt = 0; kt < 3; ++kt) {
+                float wf[2][32];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    load_wfrag<8>(a.conv_center, 384, 128 * g + 32 * wv + 16 * cb, 128 * kt, 384, wf[cb], lane);
+                mma_tile<8, 2>(tX[kt], wf, acc, lane);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    st4(tY[g] + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), relu4(acc[rb][cb]));
+        }
+        __syncthreads();
+
+        {   // 384 -> 64, relu; wavefront w owns columns 16w..16w+15 -> tX[0][:, 0:64]
+            f4 acc[3][1];
+            const f4 b = ld4(a.b1 + 16 * wv + 4 * q);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b;
+            for (int kt = 0; kt < 3; ++kt) {
+                float wf[1][32];
+                load_wfrag<8>(a.w1, 384, 16 * wv, 128 * kt, 64, wf[0], lane);
+                mma_tile<8, 1>(tY[kt], wf, acc, lane);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) st4(tX[0] + chunk_off(16 * rb + m, 4 * wv + q), relu4(acc[rb][0]));
+        }
+        __syncthreads();
+        if (wv < 2) {   // 64 -> 32, relu -> tX[1][:, 0:32]
+            f4 acc[3][1];
+            const f4 b = ld4(a.b2 + 16 * wv + 4 * q);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b;
+            float wf[1][16];
+            load_wfrag<4>(a.w2, 64, 16 * wv, 0, 32, wf[0], lane);
+            mma_tile<4, 1>(tX[0], wf, acc, lane);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) st4(tX[1] + chunk_off(16 * rb + m, 4 * wv + q), relu4(acc[rb][0]));
+        }
+        __syncthreads();
+        if (wv < 2) {   // 32 -> 21 (rows 21..31 of the weight read as zero) -> z in tX[2][:, 0:32]
+            f4 acc[3][1];
+            f4 b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 16 * wv + 4 * q + r;
+                b[r] = n < TMPNN_VOCAB ? a.b3[n] : 0.f;
+            }
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b;
+            float wf[1][8];
+            load_wfrag<2>(a.w3, 32, 16 * wv, 0, TMPNN_VOCAB, wf[0], lane);
+            mma_tile<2, 1>(tX[1], wf, acc, lane);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) st4(tX[2] + chunk_off(16 * rb + m, 4 * wv + q), acc[rb][0]);
+        }
+        __syncthreads();
+        for (int e = tid; e < rows * TMPNN_VOCAB; e += TM_THREADS) {
+            const int row = e / TMPNN_VOCAB, aa = e - row * TMPNN_VOCAB;
+            const float z = tX[2][chunk_off(row, aa >> 2) + (aa & 3)];
+            const int wt = s_S[row];
+            const float zw = tX[2][chunk_off(row, wt >> 2) + (wt & 3)];
+            a.ddg[(size_t)(r0 + row) * TMPNN_VOCAB + aa] = (dw * z + db) - (dw * zw + db);   // :110-116
+            if (a.z_opt) a.z_opt[(size_t)(r0 + row) * TMPNN_VOCAB + aa] = z;
+        }
+        __syncthreads();
+    }
+}
+
+// log_softmax(W_out h + b): one wavefront per residue, lane a < 21 owns logit a.
+__global__ __launch_bounds__(TM_THREADS) void log_probs_kernel(const float *__restrict__ W, const float *__restrict__ b,
+                                                               const float *__restrict__ h, int T,
+                                                               float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int t = blockIdx.x * 4 + wv; t < T; t += gridDim.x * 4) {
+        float logit = -INFINITY;
+        if (lane < TMPNN_VOCAB) {
+            const float *wr = W + lane * TM_H, *hr = h + (size_t)t * TM_H;
+            float s = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < TM_H; ++k) s += wr[k] * hr[k];
+            logit = s + b[lane];
+        }
+        float mx = logit;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float e = lane < TMPNN_VOCAB ? expf(logit - mx) : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off);
+        if (lane < TMPNN_VOCAB) out[(size_t)t * TMPNN_VOCAB + lane] = (logit - mx) - logf(e);
+    }
+}
+
+__global__ __launch_bounds__(TM_THREADS) void seq_embed_kernel(const float *__restrict__ Ws, const int32_t *__restrict__ S,
+                                                               int64_t T, float *__restrict__ hS) {
+    const int64_t total = T * 32, stride = (int64_t)gridDim.x * TM_THREADS;
+    for (int64_t g = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x; g < total; g += stride) {
+        const int64_t t = g >> 5;
+        const int c = (int)(g & 31);
+        st4(hS + g * 4, ld4(Ws + S[t] * TM_H + 4 * c));
+    }
+}
+
+// derived tables, computed once per weight set
+__global__ void prep_pos_table_kernel(const float *__restrict__ pos_w, const float *__restrict__ pos_b,
+                                      const float *__restrict__ edge_w, float *__restrict__ table) {
+    const int d = blockIdx.x, n = threadIdx.x;     // 66 x 128
+    float s = 0.f;
+    for (int p = 0; p < 16; ++p) s += (pos_w[p * 66 + d] + pos_b[p]) * edge_w[n * 416 + p];
+    table[d * TM_H + n] = s;
+}
+__global__ void prep_seq_table_kernel(const float *__restrict__ Ws, const float *__restrict__ W1,
+                                      float *__restrict__ table) {
+    const int s = blockIdx.x, n = threadIdx.x;     // 21 x 128;  W1 [128,512], columns 256..383 multiply W_s[S_j]
+    float acc = 0.f;
+    for (int k = 0; k < TM_H; ++k) acc += Ws[s * TM_H + k] * W1[n * 512 + 256 + k];
+    table[s * TM_H + n] = acc;
+}
+__global__ void prep_conv_center_kernel(const float *__restrict__ conv_w, float *__restrict__ center) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 384*384
+    if (i < 384 * 384) center[i] = conv_w[(size_t)i * 9 + 4];
+}
+
+int launch_prep_tables(tmpnn_weights *w, hipStream_t st) {
+    prep_pos_table_kernel<<<66, TM_H, 0, st>>>(w->pos_w, w->pos_b, w->edge_w, w->pos_table);
+    for (int l = 0; l < 3; ++l)
+        prep_seq_table_kernel<<<TMPNN_VOCAB, TM_H, 0, st>>>(w->Ws_w, w->dec[l].W1, w->seq_table[l]);
+    if (w->n_tensors == TMPNN_N_TENSORS)
+        prep_conv_center_kernel<<<(384 * 384 + 255) / 256, 256, 0, st>>>(w->conv_w, w->conv_center);
+    return tm_check_launch("prep_tables");
+}
+
+int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg,
+                float *z_opt, hipStream_t st) {
+    HeadArgs a{w->conv_center, w->conv_b, w->mlp_w[0], w->mlp_b[0], w->mlp_w[1], w->mlp_b[1], w->mlp_w[2], w->mlp_b[2],
+               w->ddg_w, w->ddg_b, w->Ws_w, hA, hB, S, ddg, z_opt, (int)T};
+    const int64_t tiles = (T + TM_TILE - 1) / TM_TILE, cap = tm_num_cus();
+    head_kernel<<<(int)(tiles < cap ? tiles : cap), TM_THREADS, 0, st>>>(a);
+    return tm_check_launch("ddg_head");
+}
+
+int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, hipStream_t st) {
+    const int64_t blocks = (T + 3) / 4, cap = (int64_t)tm_num_cus() * 8;
+    log_probs_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Wout_w, w->Wout_b, h, (int)T, out);
+    return tm_check_launch("log_probs");
+}
+
+int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float *hS, hipStream_t st) {
+    const int64_t blocks = (T * 32 + TM_THREADS - 1) / TM_THREADS, cap = (int64_t)tm_num_cus() * 8;
+    seq_embed_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Ws_w, S, T, hS);
+    return tm_check_launch("seq_embed");
+}

@@ -1,0 +1,72 @@
+// Internal host-side declarations shared by the .hip translation units of libtmpnn.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tmpnn.h"
+
+struct EncW {   // device pointers into the raw state-dict tensors of one EncLayer
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b;
+    const float *W1, *b1, *W2, *b2, *W3, *b3, *W11, *b11, *W12, *b12, *W13, *b13;
+    const float *Win, *bin, *Wout, *bout;
+};
+struct DecW {
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    const float *Win, *bin, *Wout, *bout;
+};
+struct tmpnn_weights {
+    int n_tensors;
+    const float *t[TMPNN_N_TENSORS];
+    // features
+    const float *pos_w, *pos_b, *edge_w, *norm_edges_w, *norm_edges_b, *We_w, *We_b, *Ws_w;
+    EncW enc[3];
+    DecW dec[3];
+    const float *Wout_w, *Wout_b;
+    // head
+    const float *conv_w, *conv_b, *mlp_w[3], *mlp_b[3], *ddg_w, *ddg_b;
+    // derived tables (in the caller's packed buffer)
+    float *pos_table;      // [66,128]   (W_pos^T + b_pos) . W_edge[:, :16]^T
+    float *seq_table[3];   // [21,128]   W_s . W1_dec[l][:, 256:384]^T
+    float *conv_center;    // [384,384]  feature_convolution.weight[:, :, 4]
+};
+
+// scratch carved out of the caller's workspace for the message-passing layers
+struct LayerWs {
+    float *P;      // [T,256] node projections (A | C)
+    float *Ssum;   // [T,128] sum_k mask_k * m2_k
+    float *cnt;    // [T]     sum_k mask_k
+};
+
+int tm_set_error(int code, const char *fmt, ...);
+int tm_check_launch(const char *what);
+
+// tmpnn_graph.hip
+int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,
+               int32_t *E_idx, float *D_nb, hipStream_t st);
+int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx, const int32_t *cenc,
+                     const int32_t *E_idx, const float *D_nb, int64_t T, float *h_E, float *E_opt, hipStream_t st);
+int launch_gather_rows(const float *nodes, const void *idx, int idx64, int64_t n_rows, int64_t rows_per_batch,
+                       int64_t nodes_per_batch, int C, float *out, hipStream_t st);
+int launch_gather_edges(const float *edges, const int64_t *idx, int B, int N, int K, int C, float *out, hipStream_t st);
+
+// tmpnn_layers.hip
+int launch_node_proj(const float *h, const float *Wa, int lda, const float *ba, const float *Wc, int ldc, int64_t T,
+                     float *P, hipStream_t st);
+int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
+               const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
+               int64_t T, float *Ssum, float *cnt, hipStream_t st);
+int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
+                       const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
+                       const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,
+                       float *h_out, hipStream_t st);
+int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
+
+// tmpnn_head.hip
+int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg,
+                float *z_opt, hipStream_t st);
+int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, hipStream_t st);
+int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float *hS, hipStream_t st);
+int launch_prep_tables(tmpnn_weights *w, hipStream_t st);
+
+int tm_num_cus();

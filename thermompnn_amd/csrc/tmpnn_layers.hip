@@ -1,0 +1,422 @@
+// Message-passing layers of the ProteinMPNN encoder/decoder as hand-written gfx950 kernels.
+//
+// Reference semantics: EncLayer.forward (/root/reference/protein_mpnn_utils.py:816-839),
+// DecLayer.forward (:859-880), decoder wiring in ProteinMPNN.forward (:1238-1273).
+//
+// Schedule (parity-neutral restructuring, checked on CPU by tests/test_schedule_model.py):
+//   W1 . [h_i | e_ij | h_j]  =  (W1a h_i + b1) + W1b e_ij + W1c h_j      node terms once per NODE (node_proj)
+//   sum_k m_k (W3 x_k + b3)  =  W3 (sum_k m_k x_k) + b3 sum_k m_k        W3 once per NODE (node_update)
+// so the per-EDGE work is two (message) or three (edge update) 128x128 GEMMs on the matrix cores, with
+// the weight slices resident in VGPRs for the whole kernel and the residue's 48-slot neighbour list +
+// edge tile staged in LDS. Per-node aggregation over K is an in-workgroup column reduction
+// (deterministic; no atomics).
+#include "tmpnn_common.h"
+#include "tmpnn_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// node_proj: P[t, 0:128] = Wa h_t + ba ; P[t, 128:256] = Wc h_t            (48 residues per tile)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TM_THREADS, 2) void node_proj_kernel(const float *__restrict__ h,
+                                                                  const float *__restrict__ Wa, int lda,
+                                                                  const float *__restrict__ ba,
+                                                                  const float *__restrict__ Wc, int ldc, int T,
+                                                                  float *__restrict__ P) {
+    __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    float wa[2][32], wc[2][32];
+    f4 bias[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int n0 = 32 * wv + 16 * cb;
+        load_wfrag<8>(Wa, lda, n0, 0, TM_H, wa[cb], lane);
+        load_wfrag<8>(Wc, ldc, n0, 0, TM_H, wc[cb], lane);
+        bias[cb] = ld4(ba + n0 + 4 * q);
+    }
+    const int n_tiles = (T + TM_TILE - 1) / TM_TILE;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int r0 = tile * TM_TILE;
+        load_tile(tA, h + (size_t)r0 * TM_H, min(TM_TILE, T - r0), tid);
+        __syncthreads();
+        f4 acc[3][2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {      // A half (with bias), then C half
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = half ? f4{0.f, 0.f, 0.f, 0.f} : bias[cb];
+            if (half) mma_tile<8, 2>(tA, wc, acc, lane);
+            else mma_tile<8, 2>(tA, wa, acc, lane);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                const int row = r0 + 16 * rb + m;
+                if (row < T) {
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        st4(P + (size_t)row * 256 + 128 * half + 32 * wv + 16 * cb + 4 * q, acc[rb][cb]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// msg: per residue i (tile = its 48 neighbour slots):  Ssum_i = sum_k ma_ik * gelu(W2 gelu(pre_ik) + b2)
+//   encoder: pre = A_i + C_j + W1b e_ij                  ma = mask_i mask_j   (EncLayer :819-825, :1232-1233)
+//   decoder: pre = A_i + mask_i (W1b e_ij + SeqT[S_j] + D_j)   ma = 1         (DecLayer :863-870, :1270-1272)
+// ------------------------------------------------------------------------------------------------
+struct MsgArgs {
+    const float *W1e; int ld1;
+    const float *W2, *b2;
+    const float *P;          // [T,256]: A (bias folded) | C or D
+    const float *seq_table;  // [21,128] decoder only
+    const int32_t *S;
+    const float *hE;         // [T,48,128]
+    const int32_t *E_idx;    // [T,48]
+    const float *mask;       // [T]
+    float *Ssum, *cnt;
+    int T;
+};
+
+template <bool DEC>
+__global__ __launch_bounds__(TM_THREADS, 2) void msg_kernel(MsgArgs a) {
+    __shared__ __attribute__((aligned(16))) float tE[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
+    __shared__ float s_part[TM_H];
+    __shared__ int s_idx[TM_TILE];
+    __shared__ float s_ma[TM_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+
+    float w1[2][32], w2[2][32];
+    f4 bias2[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int n0 = 32 * wv + 16 * cb;
+        load_wfrag<8>(a.W1e, a.ld1, n0, 0, TM_H, w1[cb], lane);
+        load_wfrag<8>(a.W2, TM_H, n0, 0, TM_H, w2[cb], lane);
+        bias2[cb] = ld4(a.b2 + n0 + 4 * q);
+    }
+
+    for (int i = blockIdx.x; i < a.T; i += gridDim.x) {
+        const float mi = a.mask[i];
+        if (tid < TM_TILE) {
+            const int j = a.E_idx[(size_t)i * TM_KS + tid];
+            s_idx[tid] = j;
+            s_ma[tid] = j < 0 ? 0.f : (DEC ? 1.f : mi * a.mask[j]);
+        }
+        load_tile(tE, a.hE + (size_t)i * TM_KS * TM_H, TM_TILE, tid);
+        __syncthreads();
+
+        f4 acc[3][2];
+        int jrow[3];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int j = s_idx[16 * rb + m];
+            jrow[rb] = j < 0 ? i : j;
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int n = 32 * wv + 16 * cb + 4 * q;
+            if (DEC) {
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = f4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const f4 ai = ld4(a.P + (size_t)i * 256 + n);
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = ai + ld4(a.P + (size_t)jrow[rb] * 256 + 128 + n);
+            }
+        }
+        mma_tile<8, 2>(tE, w1, acc, lane);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int n = 32 * wv + 16 * cb + 4 * q;
+            f4 ai;
+            if (DEC) ai = ld4(a.P + (size_t)i * 256 + n);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                f4 v = acc[rb][cb];
+                if (DEC) {
+                    const int j = jrow[rb];
+                    v = ai + mi * (v + ld4(a.seq_table + a.S[j] * TM_H + n) + ld4(a.P + (size_t)j * 256 + 128 + n));
+                }
+                st4(tA + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(v));
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = bias2[cb];
+        mma_tile<8, 2>(tA, w2, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const float ma = s_ma[16 * rb + m];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                f4 v = gelu4(acc[rb][cb]) * ma;
+                if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
+                st4(tE + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), v);
+            }
+        }
+        __syncthreads();
+
+        // per-node aggregation over the 48 slots: column sums, two 24-row halves
+        {
+            const int n = tid & 127, half = tid >> 7;
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 24 * half; r < 24 * half + 24; ++r) s += tE[chunk_off(r, n >> 2) + (n & 3)];
+            if (half) s_part[n] = s;
+            __syncthreads();
+            if (!half) a.Ssum[(size_t)i * TM_H + n] = s + s_part[n];
+            if (tid == 128) {
+                float c = 0.f;
+                for (int r = 0; r < TM_TILE; ++r) c += s_ma[r];
+                a.cnt[i] = c;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// enc_edge: e_ij <- LN3(e_ij + W13 gelu(W12 gelu(A'_i + C'_j + W11b e_ij) + b12) + b13)   (EncLayer :834-838)
+// ------------------------------------------------------------------------------------------------
+struct EdgeArgs {
+    const float *W11e;  // W11[:, 128:256], ld 384
+    const float *W12, *b12, *W13, *b13, *g3, *be3;
+    const float *P;     // [T,256]
+    float *hE;
+    const int32_t *E_idx;
+    int T;
+};
+
+__global__ __launch_bounds__(TM_THREADS, 1) void enc_edge_kernel(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float tE[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];
+    __shared__ int s_idx[TM_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+
+    float w11[2][32], w12[2][32], w13[2][32];
+    f4 b12[2], b13[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int n0 = 32 * wv + 16 * cb;
+        load_wfrag<8>(a.W11e, 384, n0, 0, TM_H, w11[cb], lane);
+        load_wfrag<8>(a.W12, TM_H, n0, 0, TM_H, w12[cb], lane);
+        load_wfrag<8>(a.W13, TM_H, n0, 0, TM_H, w13[cb], lane);
+        b12[cb] = ld4(a.b12 + n0 + 4 * q);
+        b13[cb] = ld4(a.b13 + n0 + 4 * q);
+    }
+    const int c32 = lane & 31;
+    const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
+
+    for (int i = blockIdx.x; i < a.T; i += gridDim.x) {
+        if (tid < TM_TILE) s_idx[tid] = a.E_idx[(size_t)i * TM_KS + tid];
+        float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
+        load_tile(tE, tile_g, TM_TILE, tid);
+        __syncthreads();
+
+        f4 acc[3][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int n = 32 * wv + 16 * cb + 4 * q;
+            const f4 ai = ld4(a.P + (size_t)i * 256 + n);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                const int j = s_idx[16 * rb + m];
+                acc[rb][cb] = ai + ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + n);
+            }
+        }
+        mma_tile<8, 2>(tE, w11, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) st4(tA + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(acc[rb][cb]));
+        __syncthreads();
+
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = b12[cb];
+        mma_tile<8, 2>(tA, w12, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) st4(tB + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(acc[rb][cb]));
+        __syncthreads();
+
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = b13[cb];
+        mma_tile<8, 2>(tB, w13, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int off = chunk_off(16 * rb + m, 8 * wv + 4 * cb + q);
+                st4(tA + off, ld4(tE + off) + acc[rb][cb]);     // residual
+            }
+        __syncthreads();
+
+        // row phase: half-wavefront per edge row, LayerNorm, coalesced 512-byte stores
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int row = 12 * wv + 2 * it + (lane >> 5);
+            const f4 y = layer_norm_row(ld4(tA + chunk_off(row, c32)), g4, be4);
+            if (s_idx[row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node_update:  h <- mask * LN2(h1 + FFN(h1)),  h1 = LN1(h + (W3 Ssum + cnt b3) / 30)
+//   (EncLayer :826-832 / DecLayer :870-879; PositionWiseFeedForward :883-893)          48 residues per tile
+// ------------------------------------------------------------------------------------------------
+struct NodeArgs {
+    const float *W3, *b3, *n1w, *n1b, *Win, *bin, *Wout, *bout, *n2w, *n2b;
+    const float *h_in, *Ssum, *cnt, *mask;
+    float *h_out;
+    int T;
+};
+
+__global__ __launch_bounds__(TM_THREADS, 2) void node_update_kernel(NodeArgs a) {
+    __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int c32 = lane & 31;
+    const int n_tiles = (a.T + TM_TILE - 1) / TM_TILE;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int r0 = tile * TM_TILE;
+        load_tile(tA, a.Ssum + (size_t)r0 * TM_H, min(TM_TILE, a.T - r0), tid);
+        __syncthreads();
+
+        float wf[2][32];
+        f4 acc[3][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) load_wfrag<8>(a.W3, TM_H, 32 * wv + 16 * cb, 0, TM_H, wf[cb], lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f4{0.f, 0.f, 0.f, 0.f};
+        mma_tile<8, 2>(tA, wf, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int row = r0 + 16 * rb + m;
+            const bool ok = row < a.T;
+            const float c = ok ? a.cnt[row] : 0.f;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int n = 32 * wv + 16 * cb + 4 * q;
+                const f4 hv = ok ? ld4(a.h_in + (size_t)row * TM_H + n) : f4{0.f, 0.f, 0.f, 0.f};
+                const f4 dh = (acc[rb][cb] + c * ld4(a.b3 + n)) / 30.0f;
+                st4(tB + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), hv + dh);
+            }
+        }
+        __syncthreads();
+        {   // LN1 in place
+            const f4 g4 = ld4(a.n1w + 4 * c32), b4 = ld4(a.n1b + 4 * c32);
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int row = 12 * wv + 2 * it + (lane >> 5);
+                float *p = tB + chunk_off(row, c32);
+                st4(p, layer_norm_row(ld4(p), g4, b4));
+            }
+        }
+        __syncthreads();
+
+        f4 out[3][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const f4 b = ld4(a.bout + 32 * wv + 16 * cb + 4 * q);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) out[rb][cb] = b;
+        }
+        for (int c = 0; c < 4; ++c) {           // FFN hidden 512 in four 128-wide chunks
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int n0 = 128 * c + 32 * wv + 16 * cb;
+                load_wfrag<8>(a.Win, TM_H, n0, 0, 512, wf[cb], lane);
+                const f4 b = ld4(a.bin + n0 + 4 * q);
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = b;
+            }
+            mma_tile<8, 2>(tB, wf, acc, lane);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    st4(tA + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(acc[rb][cb]));
+            __syncthreads();
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) load_wfrag<8>(a.Wout, 512, 32 * wv + 16 * cb, 128 * c, TM_H, wf[cb], lane);
+            mma_tile<8, 2>(tA, wf, out, lane);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int off = chunk_off(16 * rb + m, 8 * wv + 4 * cb + q);
+                st4(tA + off, ld4(tB + off) + out[rb][cb]);
+            }
+        __syncthreads();
+        {   // LN2, mask, coalesced store
+            const f4 g4 = ld4(a.n2w + 4 * c32), b4 = ld4(a.n2b + 4 * c32);
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int row = 12 * wv + 2 * it + (lane >> 5);
+                const int grow = r0 + row;
+                const f4 y = layer_norm_row(ld4(tA + chunk_off(row, c32)), g4, b4);
+                if (grow < a.T) st4(a.h_out + (size_t)grow * TM_H + 4 * c32, y * a.mask[grow]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+static int grid_for(int64_t work_items, int blocks_per_cu) {
+    const int64_t cap = (int64_t)tm_num_cus() * blocks_per_cu;
+    return (int)(work_items < cap ? (work_items < 1 ? 1 : work_items) : cap);
+}
+
+int launch_node_proj(const float *h, const float *Wa, int lda, const float *ba, const float *Wc, int ldc, int64_t T,
+                     float *P, hipStream_t st) {
+    const int64_t tiles = (T + TM_TILE - 1) / TM_TILE;
+    node_proj_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(h, Wa, lda, ba, Wc, ldc, (int)T, P);
+    return tm_check_launch("node_proj");
+}
+
+int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
+               const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
+               int64_t T, float *Ssum, float *cnt, hipStream_t st) {
+    MsgArgs a{W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, Ssum, cnt, (int)T};
+    const int grid = grid_for(T, 2);
+    if (dec) msg_kernel<true><<<grid, TM_THREADS, 0, st>>>(a);
+    else msg_kernel<false><<<grid, TM_THREADS, 0, st>>>(a);
+    return tm_check_launch(dec ? "dec_msg" : "enc_msg");
+}
+
+int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
+    EdgeArgs a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
+    enc_edge_kernel<<<grid_for(T, 1), TM_THREADS, 0, st>>>(a);
+    return tm_check_launch("enc_edge");
+}
+
+int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
+                       const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
+                       const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,
+                       float *h_out, hipStream_t st) {
+    NodeArgs a{W3, b3, n1w, n1b, Win, bin, Wout, bout, n2w, n2b, h_in, Ssum, cnt, mask, h_out, (int)T};
+    const int64_t tiles = (T + TM_TILE - 1) / TM_TILE;
+    node_update_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a);
+    return tm_check_launch("node_update");
+}

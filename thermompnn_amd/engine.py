@@ -1,0 +1,217 @@
+"""Thin Python glue over the C-ABI: torch owns device memory and streams (plumbing), libtmpnn.so does
+all arithmetic. Every method takes/returns torch CUDA tensors and launches on the current stream."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import HID, KS, VOCAB, TmpnnError, check
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise TmpnnError("the ThermoMPNN HIP engine needs CUDA (ROCm) tensors; there is no CPU path")
+
+
+class Weights:
+    """Device-resident weight set + the native handle (tmpnn_weights_create)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device, with_head: Optional[bool] = None):
+        lib = _lib.load()
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise TmpnnError("weights must live on a CUDA (ROCm) device")
+        names = _lib.tensor_names()
+        sd = dict(state_dict)
+        if with_head is None:
+            with_head = all(n in sd for n in names[_lib.N_MPNN_TENSORS:])
+        n = _lib.N_TENSORS if with_head else _lib.N_MPNN_TENSORS
+        self.tensors: List[torch.Tensor] = []
+        for i, name in enumerate(names[:n]):
+            key = name if i >= _lib.N_MPNN_TENSORS else ("prot_mpnn." + name if ("prot_mpnn." + name) in sd else name)
+            if key not in sd:
+                raise KeyError(f"state dict lacks {key!r}")
+            t = sd[key].detach().to(device=device, dtype=torch.float32).contiguous()
+            if t.numel() != lib.tmpnn_tensor_numel(i):
+                raise TmpnnError(f"{key}: {t.numel()} elements, engine expects {lib.tmpnn_tensor_numel(i)}")
+            if t.data_ptr() % 16:
+                t = t.clone()
+            self.tensors.append(t)
+        self.device = device
+        self.with_head = with_head
+        self.packed = torch.empty(lib.tmpnn_weights_packed_bytes(), dtype=torch.uint8, device=device)
+        arr = (C.c_void_p * n)(*[t.data_ptr() for t in self.tensors])
+        self.handle = C.c_void_p()
+        with torch.cuda.device(device):
+            check(lib.tmpnn_weights_create(C.byref(self.handle), arr, n, _ptr(self.packed), self.packed.numel(), _stream()),
+                  "tmpnn_weights_create")
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            _lib.load().tmpnn_weights_destroy(h)
+            self.handle = None
+
+
+class Engine:
+    """One weight set on one GPU. All tensors are packed along the residue axis (T = sum of lengths)."""
+
+    def __init__(self, state_dict, device="cuda", k_neighbors: int = 48):
+        self.lib = _lib.load()
+        self.w = Weights(state_dict, device)
+        self.device = self.w.device
+        if not 1 <= int(k_neighbors) <= KS:
+            raise TmpnnError(f"k_neighbors={k_neighbors} outside [1, {KS}]")
+        self.K = int(k_neighbors)
+        self._ws: Optional[torch.Tensor] = None
+
+    # -- buffers ---------------------------------------------------------------------------------
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _i32(self, t) -> torch.Tensor:
+        return torch.as_tensor(t).to(device=self.device, dtype=torch.int32).contiguous()
+
+    def _f32(self, t) -> torch.Tensor:
+        return torch.as_tensor(t).to(device=self.device, dtype=torch.float32).contiguous()
+
+    # -- individual operators (parity tests drive these) --------------------------------------------
+    def knn_topk(self, X, mask, offsets, max_len: Optional[int] = None):
+        X, mask, offsets = self._f32(X), self._f32(mask), self._i32(offsets)
+        T, N = X.shape[0], offsets.numel() - 1
+        if max_len is None:
+            max_len = int((offsets[1:] - offsets[:-1]).max().item()) if N else 0
+        E_idx = torch.empty((T, KS), dtype=torch.int32, device=self.device)
+        D_nb = torch.empty((T, KS), dtype=torch.float32, device=self.device)
+        check(self.lib.tmpnn_knn_topk(_ptr(X), _ptr(mask), _ptr(offsets), N, T, max_len, self.K, _ptr(E_idx), _ptr(D_nb),
+                                      _stream()), "tmpnn_knn_topk")
+        return E_idx, D_nb
+
+    def edge_featurize(self, X, residue_idx, chain_enc, E_idx, D_nb, want_E: bool = False):
+        X, ridx, cenc = self._f32(X), self._i32(residue_idx), self._i32(chain_enc)
+        T = X.shape[0]
+        h_E = torch.empty((T, KS, HID), dtype=torch.float32, device=self.device)
+        E = torch.empty_like(h_E) if want_E else None
+        check(self.lib.tmpnn_edge_featurize(self.w.handle, _ptr(X), _ptr(ridx), _ptr(cenc), _ptr(E_idx), _ptr(D_nb), T,
+                                            _ptr(h_E), _ptr(E), _stream()), "tmpnn_edge_featurize")
+        return (h_E, E) if want_E else h_E
+
+    def enc_layer(self, layer: int, h_V, h_E, E_idx, mask):
+        T = h_V.shape[0]
+        ws = self._workspace(self.lib.tmpnn_layer_workspace_bytes(T))
+        check(self.lib.tmpnn_enc_layer(self.w.handle, layer, _ptr(h_V), _ptr(h_E), _ptr(E_idx), _ptr(mask), T, _ptr(ws),
+                                       ws.numel(), _stream()), "tmpnn_enc_layer")
+        return h_V, h_E
+
+    def dec_layer(self, layer: int, h_V, h_E, E_idx, S, mask):
+        T = h_V.shape[0]
+        out = torch.empty_like(h_V)
+        ws = self._workspace(self.lib.tmpnn_layer_workspace_bytes(T))
+        check(self.lib.tmpnn_dec_layer(self.w.handle, layer, _ptr(h_V), _ptr(out), _ptr(h_E), _ptr(E_idx), _ptr(S),
+                                       _ptr(mask), T, _ptr(ws), ws.numel(), _stream()), "tmpnn_dec_layer")
+        return out
+
+    def seq_embed(self, S):
+        S = self._i32(S)
+        out = torch.empty((S.numel(), HID), dtype=torch.float32, device=self.device)
+        check(self.lib.tmpnn_seq_embed(self.w.handle, _ptr(S), S.numel(), _ptr(out), _stream()), "tmpnn_seq_embed")
+        return out
+
+    def log_probs(self, h_V):
+        out = torch.empty((h_V.shape[0], VOCAB), dtype=torch.float32, device=self.device)
+        check(self.lib.tmpnn_log_probs(self.w.handle, _ptr(h_V), h_V.shape[0], _ptr(out), _stream()), "tmpnn_log_probs")
+        return out
+
+    def ddg_head(self, hV_last, hV_prev, S, want_z: bool = False):
+        S = self._i32(S)
+        T = S.numel()
+        ddg = torch.empty((T, VOCAB), dtype=torch.float32, device=self.device)
+        z = torch.empty_like(ddg) if want_z else None
+        check(self.lib.tmpnn_ddg_head(self.w.handle, _ptr(hV_last), _ptr(hV_prev), _ptr(S), T, _ptr(ddg), _ptr(z),
+                                      _stream()), "tmpnn_ddg_head")
+        return (ddg, z) if want_z else ddg
+
+    def gather_rows(self, nodes, idx_i32):
+        nodes = nodes.contiguous()
+        idx = idx_i32.contiguous()
+        out = torch.empty((idx.numel(), nodes.shape[-1]), dtype=torch.float32, device=nodes.device)
+        check(self.lib.tmpnn_gather_rows_i32(_ptr(nodes), _ptr(idx), idx.numel(), nodes.shape[-1], _ptr(out), _stream()),
+              "tmpnn_gather_rows_i32")
+        return out
+
+    # -- the fused path -----------------------------------------------------------------------------
+    def ssm_forward(self, X, S, mask, residue_idx, chain_enc, offsets, max_len: Optional[int] = None,
+                    want_ddg: bool = True, want_hidden: bool = False, want_log_probs: bool = False,
+                    want_E_idx: bool = False, out: Optional[dict] = None):
+        """Packed inputs ([T,4,3], [T], ...) -> dict(ddg [T,21], hidden [3,T,128], log_probs [T,21], E_idx [T,48])."""
+        X, mask = self._f32(X), self._f32(mask)
+        S, ridx, cenc, offsets = self._i32(S), self._i32(residue_idx), self._i32(chain_enc), self._i32(offsets)
+        _need_cuda(X, S, mask)
+        T, N = X.shape[0], offsets.numel() - 1
+        if max_len is None:
+            max_len = int((offsets[1:] - offsets[:-1]).max().item()) if N else 0
+        res = out if out is not None else {}
+        dev = self.device
+        if want_ddg and "ddg" not in res:
+            res["ddg"] = torch.empty((T, VOCAB), dtype=torch.float32, device=dev)
+        if want_hidden and "hidden" not in res:
+            res["hidden"] = torch.empty((3, T, HID), dtype=torch.float32, device=dev)
+        if want_log_probs and "log_probs" not in res:
+            res["log_probs"] = torch.empty((T, VOCAB), dtype=torch.float32, device=dev)
+        if want_E_idx and "E_idx" not in res:
+            res["E_idx"] = torch.empty((T, KS), dtype=torch.int32, device=dev)
+        ws = self._workspace(self.lib.tmpnn_workspace_bytes(T))
+        check(self.lib.tmpnn_ssm_forward(self.w.handle, _ptr(X), _ptr(S), _ptr(mask), _ptr(ridx), _ptr(cenc), _ptr(offsets),
+                                         N, T, max_len, self.K, _ptr(res.get("ddg") if want_ddg else None),
+                                         _ptr(res.get("hidden") if want_hidden else None),
+                                         _ptr(res.get("log_probs") if want_log_probs else None),
+                                         _ptr(res.get("E_idx") if want_E_idx else None), _ptr(ws), ws.numel(), _stream()),
+              "tmpnn_ssm_forward")
+        return res
+
+
+# module-level gathers with the reference's signatures (protein_mpnn_utils.py:763-791)
+def gather_nodes(nodes: torch.Tensor, neighbor_idx: torch.Tensor) -> torch.Tensor:
+    _need_cuda(nodes, neighbor_idx)
+    lib = _lib.load()
+    B, N, C_ = nodes.shape
+    K = neighbor_idx.shape[2]
+    src = nodes.to(torch.float32).contiguous()
+    idx = neighbor_idx.to(torch.int64).contiguous()
+    out = torch.empty((B, idx.shape[1], K, C_), dtype=torch.float32, device=nodes.device)
+    with torch.cuda.device(nodes.device):
+        check(lib.tmpnn_gather_nodes(_ptr(src), _ptr(idx), B, N, K, C_, _ptr(out), _stream()), "tmpnn_gather_nodes")
+    return out.to(nodes.dtype)
+
+
+def gather_edges(edges: torch.Tensor, neighbor_idx: torch.Tensor) -> torch.Tensor:
+    _need_cuda(edges, neighbor_idx)
+    lib = _lib.load()
+    B, N, _, C_ = edges.shape
+    K = neighbor_idx.shape[2]
+    src = edges.to(torch.float32).contiguous()
+    idx = neighbor_idx.to(torch.int64).contiguous()
+    out = torch.empty((B, N, K, C_), dtype=torch.float32, device=edges.device)
+    with torch.cuda.device(edges.device):
+        check(lib.tmpnn_gather_edges(_ptr(src), _ptr(idx), B, N, K, C_, _ptr(out), _stream()), "tmpnn_gather_edges")
+    return out.to(edges.dtype)
+
+
+def cat_neighbors_nodes(h_nodes, h_neighbors, E_idx):
+    return torch.cat([h_neighbors, gather_nodes(h_nodes, E_idx)], -1)

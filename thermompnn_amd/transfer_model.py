@@ -1,0 +1,102 @@
+"""Drop-in counterpart of /root/reference/transfer_model.py: get_protein_mpnn + TransferModel.
+
+``model(pdb, mutations)`` keeps the reference contract (transfer_model.py:75-121): a list aligned with
+``mutations`` holding ``{"ddG": Tensor[1]}`` (on the model's device) or ``None``, and ``None`` as the
+second return value. Internally ONE fused forward produces the whole [L, 21] ddG table.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from . import weights as _weights
+from .datasets import ALPHABET
+from .pdb_io import tied_featurize
+from .protein_mpnn_utils import ProteinMPNN, _EngineOwner, _register_tree
+
+HIDDEN_DIM = 128
+EMBED_DIM = 128
+VOCAB_DIM = 21
+
+
+def _cfg_get(node, key, default=None):
+    try:
+        return node[key] if key in node else default
+    except TypeError:
+        return getattr(node, key, default)
+
+
+def get_protein_mpnn(cfg, version="v_48_020.pt"):
+    """Load vanilla ProteinMPNN weights (transfer_model.py:17-37): ``{thermompnn_dir}/vanilla_model_weights/{version}``
+    holding ``num_edges`` and ``model_state_dict``."""
+    path = os.path.join(cfg.platform.thermompnn_dir, "vanilla_model_weights", version)
+    num_edges, sd = _weights.load_vanilla_checkpoint(path)
+    model = ProteinMPNN(ca_only=False, num_letters=21, node_features=HIDDEN_DIM, edge_features=HIDDEN_DIM,
+                        hidden_dim=HIDDEN_DIM, num_encoder_layers=3, num_decoder_layers=3, k_neighbors=num_edges,
+                        augment_eps=0.0)
+    if cfg.model.load_pretrained:
+        model.load_state_dict(sd)
+    if cfg.model.freeze_weights:
+        model.eval()
+        for p in model.parameters():
+            p.requires_grad = False
+    return model
+
+
+class TransferModel(_EngineOwner):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.hidden_dims = list(cfg.model.hidden_dims)
+        self.subtract_mut = cfg.model.subtract_mut
+        self.num_final_layers = cfg.model.num_final_layers
+        self.lightattn = _cfg_get(cfg.model, "lightattn", False)
+        if "decoding_order" not in self.cfg:                      # the reference writes this back (:50-51)
+            self.cfg.decoding_order = "left-to-right"
+        if self.hidden_dims != [64, 32] or self.num_final_layers != 2 or not self.lightattn:
+            raise NotImplementedError("the HIP head is specialised for the released ThermoMPNN configuration "
+                                      "(hidden_dims [64, 32], num_final_layers 2, lightattn true; config.yaml:15-21)")
+        self.prot_mpnn = get_protein_mpnn(cfg)
+        self.k_neighbors = self.prot_mpnn.k_neighbors
+        _register_tree(self, _weights.head_param_shapes(self.hidden_dims))
+        with torch.no_grad():                                      # nn.Linear(1, 1)-like non-degenerate default
+            self.ddg_out.weight.fill_(1.0)
+
+    def forward(self, pdb, mutations, tied_feat=True):
+        device = next(self.parameters()).device
+        feats = tied_featurize([pdb[0]], device, None, None, None, None, None, None, ca_only=False)
+        X, S, mask, chain_enc, residue_idx = feats[0], feats[1], feats[2], feats[5], feats[12]
+        eng = self.engine()
+        L = X.shape[1]
+        with torch.cuda.device(eng.device):
+            res = eng.ssm_forward(X[0], S[0], mask[0], residue_idx[0], chain_enc[0],
+                                  torch.tensor([0, L], dtype=torch.int32), max_len=L, want_hidden=True)
+            ddg = res["ddg"]                                        # [L,21]: (w z_a + b) - (w z_wt + b), wt = S
+            pos, aa, wt = [], [], []
+            for m in mutations:
+                if m is not None:
+                    pos.append(m.position)
+                    aa.append(ALPHABET.index(m.mutation))
+                    wt.append(ALPHABET.index(m.wildtype))
+            if not pos:
+                return [None for _ in mutations], None
+            pos_t = torch.tensor(pos, device=device)
+            aa_t = torch.tensor(aa, device=device)
+            wt_t = torch.tensor(wt, device=device)
+            if self.subtract_mut and bool((S[0][pos_t] == wt_t).all()):
+                vals = ddg[pos_t, aa_t]
+            else:   # a stated wild type that differs from the structure, or subtract_mut=False: use z directly
+                hid = res["hidden"]
+                _, z = eng.ddg_head(hid[2], hid[1], S[0], want_z=True)
+                zz = z * self.ddg_out.weight.view(()) + self.ddg_out.bias.view(())
+                vals = zz[pos_t, aa_t] - zz[pos_t, wt_t] if self.subtract_mut else zz[pos_t, aa_t]
+        out, k = [], 0
+        for m in mutations:
+            if m is None:
+                out.append(None)
+            else:
+                out.append({"ddG": vals[k:k + 1]})
+                k += 1
+        return out, None
