@@ -64,12 +64,21 @@ def backbone_atoms(X: Tensor) -> List[Tensor]:
     return [n, ca, c, o, cb]
 
 
-def knn(ca: Tensor, mask: Tensor, top_k: int, eps: float = 1e-6):
-    """Masked Ca distances and the top_k smallest per row (protein_mpnn_utils.py:1101-1109)."""
+def adjusted_distances(ca: Tensor, mask: Tensor, eps: float = 1e-6) -> Tensor:
+    """D_adjust of ProteinFeatures._dist (protein_mpnn_utils.py:1102-1106)."""
     m2 = mask.unsqueeze(1) * mask.unsqueeze(2)
     d = ca.unsqueeze(1) - ca.unsqueeze(2)
     D = m2 * torch.sqrt((d ** 2).sum(3) + eps)
-    D_adj = D + (1.0 - m2) * D.max(-1, keepdim=True)[0]
+    return D + (1.0 - m2) * D.max(-1, keepdim=True)[0]
+
+
+def knn(ca: Tensor, mask: Tensor, top_k: int, E_idx_override: Optional[Tensor] = None):
+    """Masked Ca distances and the top_k smallest per row (protein_mpnn_utils.py:1101-1109).
+    torch.topk leaves the order of EXACT ties unspecified; tests that must compare downstream tensors
+    slot by slot pass ``E_idx_override`` (a graph already checked to be a valid top-k) to pin it."""
+    D_adj = adjusted_distances(ca, mask)
+    if E_idx_override is not None:
+        return torch.gather(D_adj, 2, E_idx_override), E_idx_override
     return torch.topk(D_adj, min(top_k, ca.shape[1]), dim=-1, largest=False)
 
 
@@ -87,10 +96,10 @@ def positional_index(residue_idx: Tensor, chain_labels: Tensor, E_idx: Tensor, m
 
 
 def protein_features(W: Dict[str, Tensor], X: Tensor, mask: Tensor, residue_idx: Tensor,
-                     chain_labels: Tensor, top_k: int):
+                     chain_labels: Tensor, top_k: int, E_idx_override: Optional[Tensor] = None):
     """kNN graph + [posenc16 || RBF400] -> LN(W_edge .) (protein_mpnn_utils.py:1127-1180)."""
     atoms = backbone_atoms(X)
-    D_nb, E_idx = knn(atoms[CA], mask, top_k)
+    D_nb, E_idx = knn(atoms[CA], mask, top_k, E_idx_override)
     blocks = [rbf(D_nb)]
     for a, b in PAIR_ORDER[1:]:
         A, Bt = atoms[a], atoms[b]
@@ -137,11 +146,12 @@ def dec_layer(W, p: str, h_V: Tensor, h_ESV: Tensor, mask: Tensor):
 
 
 def mpnn_forward(W: Dict[str, Tensor], X, S, mask, chain_M, residue_idx, chain_encoding_all,
-                 top_k: int = 48, n_enc: int = 3, n_dec: int = 3, trace: Optional[dict] = None):
+                 top_k: int = 48, n_enc: int = 3, n_dec: int = 3, trace: Optional[dict] = None,
+                 E_idx_override: Optional[Tensor] = None):
     """ProteinMPNN.forward (protein_mpnn_utils.py:1222-1277) on the ThermoMPNN path:
     order_mask_backward is overwritten with ones (:1259), so mask_bw = mask_i, mask_fw = 0 and the
     encoder-only branch contributes exact zeros.  Returns (reversed hidden list, h_S, log_probs)."""
-    E, E_idx, D_nb = protein_features(W, X, mask, residue_idx, chain_encoding_all, top_k)
+    E, E_idx, D_nb = protein_features(W, X, mask, residue_idx, chain_encoding_all, top_k, E_idx_override)
     h_V = torch.zeros(E.shape[0], E.shape[1], E.shape[-1])
     h_E = linear(E, W, "W_e")
     if trace is not None:
@@ -221,10 +231,11 @@ def head_table(W, hidden: List[Tensor], h_S: Tensor, S: Tensor):
     return z, zz - torch.gather(zz, -1, S.unsqueeze(-1))
 
 
-def ssm_table(W, X, S, mask, chain_M, residue_idx, chain_enc, top_k: int = 48, trace=None):
+def ssm_table(W, X, S, mask, chain_M, residue_idx, chain_enc, top_k: int = 48, trace=None, E_idx_override=None):
     """Full SSM, vectorised: -> ddg[B, L, 21] (column a = mutation to ALPHABET[a])."""
     mp, hd = split_weights(W)
-    hidden, h_S, log_probs = mpnn_forward(mp, X, S, mask, chain_M, residue_idx, chain_enc, top_k, trace=trace)
+    hidden, h_S, log_probs = mpnn_forward(mp, X, S, mask, chain_M, residue_idx, chain_enc, top_k, trace=trace,
+                                          E_idx_override=E_idx_override)
     z, ddg = head_table(hd, hidden, h_S, S)
     if trace is not None:
         trace.update(h_S=h_S, log_probs=log_probs, z=z, ddg=ddg)

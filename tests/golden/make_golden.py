@@ -124,7 +124,8 @@ def main():
             "2OCJ_A_gap": (ref_utils.alt_parse_PDB(gap_path, "A")[0], 1),
             "2OCJ_AB": (ref_utils.alt_parse_PDB(pdb_path, ["A", "B"])[0], 1),
             "syn_L32": (synthetic_pdb_dict(32, seed=5), 2),
-            "syn_L256": (synthetic_pdb_dict(256, seed=0), 1),
+            "syn_L256": (synthetic_pdb_dict(256, seed=0), 1),      # BASELINE config 2; has one exact K-th-distance tie
+            "syn_L256_s1": (synthetic_pdb_dict(256, seed=1), 1),   # tie-free twin for strict end-to-end comparison
         }
         for name, (pdb, lvl) in cases.items():
             out = run_case(model, pdb, lvl)

@@ -7,7 +7,7 @@ import torch
 from conftest import load_golden
 from oracle import thermompnn_oracle as orc
 
-CASES = ["2OCJ_A", "2OCJ_A_gap", "2OCJ_AB", "syn_L32", "syn_L256"]
+CASES = ["2OCJ_A", "2OCJ_A_gap", "2OCJ_AB", "syn_L32", "syn_L256", "syn_L256_s1"]
 TOL_INTERMEDIATE = 1e-5   # abs, SURVEY §8c
 TOL_DDG = 1e-4            # kcal/mol, BASELINE.json north_star
 

@@ -346,12 +346,13 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
                                  int n_proteins, int64_t T, int max_len, int K, float *ddg, float *hidden_opt,
                                  float *log_probs_opt, int32_t *E_idx_opt, void *workspace, size_t workspace_bytes,
                                  tmpnn_stream_t stream) {
-    REQUIRE(w && X && S && mask && residue_idx && chain_enc && offsets, "ssm_forward: null input pointer");
-    REQUIRE(ddg || hidden_opt || log_probs_opt, "ssm_forward: no output requested");
-    REQUIRE(!ddg || w->n_tensors == TMPNN_N_TENSORS, "ssm_forward: ddg requested but the handle has no head tensors");
+    REQUIRE(w, "ssm_forward: null weight handle");
     REQUIRE(n_proteins >= 0 && T >= 0 && T <= T_MAX, "ssm_forward: bad sizes");
     REQUIRE(K >= 1 && K <= TMPNN_KS, "ssm_forward: K=%d outside [1, %d]", K, TMPNN_KS);
-    if (T == 0 || n_proteins == 0) return TMPNN_OK;
+    REQUIRE(!ddg || w->n_tensors == TMPNN_N_TENSORS, "ssm_forward: ddg requested but the handle has no head tensors");
+    if (T == 0 || n_proteins == 0) return TMPNN_OK;   // an empty batch is a no-op (pointers may be null)
+    REQUIRE(X && S && mask && residue_idx && chain_enc && offsets, "ssm_forward: null input pointer");
+    REQUIRE(ddg || hidden_opt || log_probs_opt, "ssm_forward: no output requested");
     if (max_len > 8192) return tm_set_error(TMPNN_E_UNSUPPORTED, "ssm_forward: max_len %d > 8192", max_len);
     hipStream_t st = (hipStream_t)stream;
 

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(TM_THREADS) void knn_kernel(const float *__restrict
             const float *c = X + (size_t)(s + j) * 12 + 3;
             const float dx = c[0] - xi, dy = c[1] - yi, dz = c[2] - zi;
             const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            const float D = __fmul_rn(mi * mask[s + j], __fsqrt_rn(__fadd_rn(s2, 1e-6f)));
+            const float D = __fmul_rn(mi * mask[s + j], sqrtf(__fadd_rn(s2, 1e-6f)));
             d[j] = D;
             dmax = fmaxf(dmax, D);
         }
