@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""ThermoMPNN SSM hot-path benchmark on MI355X (contract: python bench.py --gpus N --steps K --warmup W).
+
+A "step" = one pass of the fused HIP path (tmpnn_ssm_forward: kNN -> featurizer -> 3 enc -> 3 dec -> ddG head)
+over one batch of B synthetic proteins of L=256 residues (K=48, h=128; BASELINE.json configs[1] replicated B
+times so the 256-CU chip is filled) that is already resident in HBM, producing B*L*20 mutant ddG predictions.
+With N > 1 every rank owns its own B proteins (weak scaling, proteins are independent) and each step ends with
+the path's one exchange step: an RCCL all-gather of the per-rank ddG tables.
+
+Prints ONE JSON line on rank 0: whole-job preds/s + `roofline` (dominant kernel, HIP-event timed inside the
+timed region) + `cpu_baseline` (the CPU oracle on the host cores, bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from thermompnn_amd import _lib  # noqa: E402
+from thermompnn_amd.engine import Engine  # noqa: E402
+from thermompnn_amd.synthetic import synthetic_backbone  # noqa: E402
+from thermompnn_amd.weights import synthetic_state_dict  # noqa: E402
+
+AA20 = "ACDEFGHIKLMNPQRSTVWY"
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
+
+
+def kernel_flops(name, T, edges):
+    """Executed (algorithmic, minimal-schedule) flops of ONE launch of each kernel; DESIGN.md §5."""
+    H2 = 128 * 128
+    return {
+        "featurize": 2.0 * edges * (400 * 128 + H2),
+        "enc_msg": 2.0 * edges * 2 * H2,
+        "dec_msg": 2.0 * edges * 2 * H2,
+        "enc_edge": 2.0 * edges * 3 * H2,
+        "node_update": 2.0 * T * (H2 + 2 * 512 * 128),
+        "node_proj": 2.0 * T * 256 * 128,
+        "head": 2.0 * T * (384 * 384 + 384 * 64 + 64 * 32 + 32 * 21),
+    }.get(name)
+
+
+def build_batch(n_proteins, L, seed0, device):
+    xs, ss = [], []
+    for i in range(n_proteins):
+        X, seq = synthetic_backbone(L, seed0 + i)
+        xs.append(X)
+        ss.append([AA20.index(c) for c in seq])
+    T = n_proteins * L
+    t = lambda a, dt: torch.tensor(np.asarray(a), dtype=dt, device=device)
+    return dict(X=t(np.concatenate(xs), torch.float32), S=t(np.concatenate(ss), torch.int32),
+                mask=torch.ones(T, device=device), ridx=t(np.tile(np.arange(L), n_proteins), torch.int32),
+                cenc=torch.ones(T, dtype=torch.int32, device=device),
+                offsets=t(np.arange(n_proteins + 1) * L, torch.int32), T=T, L=L, n=n_proteins,
+                X_cpu=xs[0], S_cpu=ss[0])
+
+
+def fetch_profile(lib):
+    cap = 64
+    names = (C.c_char_p * cap)()
+    ms = (C.c_double * cap)()
+    cnt = (C.c_int64 * cap)()
+    n = lib.tmpnn_profile_fetch(names, ms, cnt, cap)
+    if n < 0:
+        raise RuntimeError(lib.tmpnn_last_error().decode())
+    return {names[i].decode(): (ms[i], cnt[i]) for i in range(n)}
+
+
+def gather_microbench(eng, device, n_nodes=16384, K=48, C_=128, iters=20):
+    """Standalone gather_nodes roofline (the 'gather HBM GB/s' of BASELINE.json:metric): out[r,:] = nodes[idx[r],:].
+    Algorithmic bytes per call = idx (int32) + node table once + output  (SURVEY §8d)."""
+    g = torch.Generator(device="cpu").manual_seed(0)
+    nodes = torch.randn(n_nodes, C_, generator=g).to(device)
+    # neighbour-like indices: each residue gathers from its own 256-residue protein
+    base = (torch.arange(n_nodes) // 256 * 256).repeat_interleave(K)
+    idx = (base + torch.randint(0, 256, (n_nodes * K,), generator=g)).to(device=device, dtype=torch.int32)
+    for _ in range(3):
+        out = eng.gather_rows(nodes, idx)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(iters):
+        out = eng.gather_rows(nodes, idx)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / iters
+    nbytes = idx.numel() * 4 + nodes.numel() * 4 + out.numel() * 4
+    # device-to-device copy of the same output size = the measured HBM roofline in this job
+    src = torch.empty_like(out)
+    for _ in range(3):
+        src.copy_(out)
+    ev0.record()
+    for _ in range(iters):
+        src.copy_(out)
+    ev1.record()
+    torch.cuda.synchronize()
+    copy_ms = ev0.elapsed_time(ev1) / iters
+    copy_gbs = 2 * out.numel() * 4 / copy_ms / 1e6
+    return {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": nbytes / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "kernel": "gather_rows (tmpnn_gather_rows_i32)",
+            "bytes_per_launch": nbytes, "ms_per_launch": ms, "rows": idx.numel(), "C": C_,
+            "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": nbytes / ms / 1e6 / copy_gbs}
+
+
+def cpu_baseline(batch, budget_s=12.0):
+    """The CPU oracle (oracle/thermompnn_oracle.py, kind 'port') on this box's host cores: full SSM of ONE
+    synthetic L=256 protein, vectorised head, repeated for ~budget_s seconds. Checker code, timed as a baseline."""
+    from oracle import thermompnn_oracle as orc
+    W = synthetic_state_dict(0)
+    L = batch["L"]
+    X = torch.tensor(batch["X_cpu"], dtype=torch.float32)[None]
+    S = torch.tensor(batch["S_cpu"])[None]
+    ones, ar = torch.ones(1, L), torch.arange(L)[None]
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        orc.ssm_table(W, X, S, ones, ones, ar, ones.long(), 48)          # warm-up
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s or reps < 3:
+            orc.ssm_table(W, X, S, ones, ones, ar, ones.long(), 48)
+            reps += 1
+        dt = time.perf_counter() - t0
+    return {"value": reps * L * 20 / dt, "unit": "preds/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x full SSM of one synthetic L={L} protein (5120 preds each), vectorised head, "
+                      f"torch CPU fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--proteins-per-gpu", type=int, default=64)
+    ap.add_argument("--length", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    lib = _lib.load()
+    eng = Engine(synthetic_state_dict(0), device, 48)
+    B, L = args.proteins_per_gpu, args.length
+    batch = build_batch(B, L, 100000 * rank, device)
+    out = {"ddg": torch.empty((batch["T"], 21), dtype=torch.float32, device=device)}
+    gathered = torch.empty((world, batch["T"], 21), dtype=torch.float32, device=device) if world > 1 else None
+
+    def step():
+        eng.ssm_forward(batch["X"], batch["S"], batch["mask"], batch["ridx"], batch["cenc"], batch["offsets"],
+                        max_len=L, out=out)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out["ddg"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    profile = not args.no_profile
+    if profile:
+        lib.tmpnn_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = fetch_profile(lib) if profile else {}
+    lib.tmpnn_profile_enable(0)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    preds_per_step = world * B * L * 20
+    result = {
+        "metric": "mutant ddG preds/sec (SSM, L=256, K=48)", "value": preds_per_step * args.steps / dt, "unit": "preds/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1] x {B}: {B} synthetic L={L} proteins per GPU (K=48, h=128), "
+                               "full 20xL SSM each, inputs resident in HBM" +
+                               ("; per-step RCCL all-gather of ddG tables" if world > 1 else ""),
+                   "proteins_per_gpu": B, "L": L, "K": 48, "h": 128, "preds_per_step": preds_per_step,
+                   "weights": "synthetic_state_dict(seed=0)", "parallelism": f"proteins sharded x{world}"},
+    }
+
+    if rank == 0:
+        T, edges = batch["T"], batch["T"] * min(48, L)
+        if prof:
+            kern = {k: {"avg_ms": ms / n, "launches": int(n), "total_ms": ms} for k, (ms, n) in prof.items()}
+            dom = max(kern, key=lambda k: kern[k]["total_ms"])
+            fl = kernel_flops(dom, T, edges)
+            achieved = fl / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+            result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": dom,
+                                  "flops_per_launch": fl, "avg_launch_ms": kern[dom]["avg_ms"],
+                                  "timed_with": "hipEvent pairs on the launch stream inside the timed region"}
+            for k, v in kern.items():
+                f = kernel_flops(k, T, edges)
+                if f:
+                    v["tflops"] = f / (v["avg_ms"] * 1e-3) / 1e12
+            result["kernels"] = kern
+            total_fl = sum(kernel_flops(k, T, edges) * v["launches"] / args.steps for k, v in kern.items() if kernel_flops(k, T, edges))
+            result["pipeline"] = {"executed_gflop_per_step": total_fl / 1e9,
+                                  "tflops_end_to_end": total_fl / (dt / args.steps) / 1e12,
+                                  "frac_of_fp32_mfma_peak": total_fl / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                  "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in kern.values()) / args.steps}
+        result["roofline_gather"] = gather_microbench(eng, device)
+        # single-protein latency (the literal configs[1]): B = 1
+        one = build_batch(1, L, 0, device)
+        o1 = {"ddg": torch.empty((L, 21), dtype=torch.float32, device=device)}
+        for _ in range(5):
+            eng.ssm_forward(one["X"], one["S"], one["mask"], one["ridx"], one["cenc"], one["offsets"], max_len=L, out=o1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            eng.ssm_forward(one["X"], one["S"], one["mask"], one["ridx"], one["cenc"], one["offsets"], max_len=L, out=o1)
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) / 50
+        result["single_protein"] = {"ms": lat * 1e3, "preds_per_s": L * 20 / lat}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(batch)
+            result["cpu_baseline"]["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

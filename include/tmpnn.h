@@ -146,6 +146,15 @@ int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const int32_t *S
                       float *log_probs_opt, int32_t *E_idx_opt, void *workspace, size_t workspace_bytes,
                       tmpnn_stream_t stream);
 
+/* ---- measurement hook ------------------------------------------------------------------------------
+ * Optional per-kernel timing with HIP events recorded on the launch stream around every kernel the
+ * library launches (bench.py's roofline leg; not thread-safe; off by default). enable(1) starts a
+ * fresh recording, enable(0) stops. fetch() waits for the recorded events, aggregates by kernel name
+ * into the caller's arrays (up to `capacity` rows, names are static strings), clears the recording and
+ * returns the number of rows (or a negative error). */
+int tmpnn_profile_enable(int on);
+int tmpnn_profile_fetch(const char **names, double *total_ms, int64_t *launches, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,61 @@ int tm_check_launch(const char *what) {
     if (e != hipSuccess) return tm_set_error(TMPNN_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return TMPNN_OK;
 }
+
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) --------
+struct ProfRec { const char *name; hipEvent_t start, stop; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;            // recorded launches since the last enable/fetch
+static std::vector<hipEvent_t> g_event_pool;   // recycled events
+
+static hipEvent_t prof_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+void tm_prof_begin(const char *name, hipStream_t st) {
+    if (!g_prof_on) return;
+    ProfRec r{name, prof_event(), prof_event()};
+    if (!r.start || !r.stop) return;
+    (void)hipEventRecord(r.start, st);
+    g_prof.push_back(r);
+}
+void tm_prof_end(hipStream_t st) {
+    if (!g_prof_on || g_prof.empty()) return;
+    (void)hipEventRecord(g_prof.back().stop, st);
+}
+
+extern "C" int tmpnn_profile_enable(int on) {
+    for (auto &r : g_prof) { g_event_pool.push_back(r.start); g_event_pool.push_back(r.stop); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return TMPNN_OK;
+}
+
+extern "C" int tmpnn_profile_fetch(const char **names, double *total_ms, int64_t *launches, int capacity) {
+    if (capacity < 0 || (capacity > 0 && (!names || !total_ms || !launches)))
+        return tm_set_error(TMPNN_E_INVALID, "profile_fetch: bad arguments");
+    std::vector<const char *> order;
+    std::map<std::string, std::pair<double, int64_t>> agg;
+    for (auto &r : g_prof) {
+        if (hipEventSynchronize(r.stop) != hipSuccess) return tm_set_error(TMPNN_E_LAUNCH, "profile_fetch: event sync failed");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) return tm_set_error(TMPNN_E_LAUNCH, "profile_fetch: elapsed failed");
+        auto it = agg.find(r.name);
+        if (it == agg.end()) { order.push_back(r.name); agg[r.name] = {ms, 1}; }
+        else { it->second.first += ms; it->second.second += 1; }
+    }
+    int n = 0;
+    for (const char *nm : order) {
+        if (n >= capacity) break;
+        names[n] = nm; total_ms[n] = agg[nm].first; launches[n] = agg[nm].second;
+        ++n;
+    }
+    for (auto &r : g_prof) { g_event_pool.push_back(r.start); g_event_pool.push_back(r.stop); }
+    g_prof.clear();
+    return n;
+}
 int tm_num_cus() {
     static int n = 0;
     if (n == 0) {

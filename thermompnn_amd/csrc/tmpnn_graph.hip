@@ -315,7 +315,7 @@ int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N,
     }
     const int64_t blocks = (T + 3) / 4;
     const int64_t cap = (int64_t)tm_num_cus() * 8;
-    knn_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb);
+    { tm_prof_begin("knn", st); knn_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb); tm_prof_end(st); }
     return tm_check_launch("knn_topk");
 }
 
@@ -328,7 +328,7 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
     for (int i = 0; i < 16; ++i)   // torch.linspace(2, 22, 16): double arithmetic, symmetric halves, cast to fp32
         a.mu[i] = i < 8 ? (float)(2.0 + (20.0 / 15.0) * i) : (float)(22.0 - (20.0 / 15.0) * (15 - i));
     const int64_t cap = tm_num_cus();
-    featurize_kernel<<<(int)(T < cap ? T : cap), TM_THREADS, 0, st>>>(a);
+    { tm_prof_begin("featurize", st); featurize_kernel<<<(int)(T < cap ? T : cap), TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
     return tm_check_launch("edge_featurize");
 }
 
@@ -339,13 +339,13 @@ int launch_gather_rows(const float *nodes, const void *idx, int idx64, int64_t n
     if (C % 4 == 0) {
         const int64_t blocks = (n_rows * (C / 4) + TM_THREADS - 1) / TM_THREADS;
         const int grid = (int)(blocks < cap ? blocks : cap);
-        if (idx64) gather_rows_kernel<int64_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int64_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C / 4, out);
-        else gather_rows_kernel<int32_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int32_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C / 4, out);
+        if (idx64) { tm_prof_begin("gather_rows", st); gather_rows_kernel<int64_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int64_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C / 4, out); tm_prof_end(st); }
+        else { tm_prof_begin("gather_rows", st); gather_rows_kernel<int32_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int32_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C / 4, out); tm_prof_end(st); }
     } else {
         const int64_t blocks = (n_rows * C + TM_THREADS - 1) / TM_THREADS;
         const int grid = (int)(blocks < cap ? blocks : cap);
-        if (idx64) gather_rows_scalar_kernel<int64_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int64_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C, out);
-        else gather_rows_scalar_kernel<int32_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int32_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C, out);
+        if (idx64) { tm_prof_begin("gather_rows_scalar", st); gather_rows_scalar_kernel<int64_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int64_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C, out); tm_prof_end(st); }
+        else { tm_prof_begin("gather_rows_scalar", st); gather_rows_scalar_kernel<int32_t><<<grid, TM_THREADS, 0, st>>>(nodes, (const int32_t *)idx, n_rows, rows_per_batch, nodes_per_batch, C, out); tm_prof_end(st); }
     }
     return tm_check_launch("gather_rows");
 }
@@ -355,6 +355,6 @@ int launch_gather_edges(const float *edges, const int64_t *idx, int B, int N, in
     if (n_rows == 0) return TMPNN_OK;
     const int64_t blocks = (n_rows * C + TM_THREADS - 1) / TM_THREADS;
     const int64_t cap = (int64_t)tm_num_cus() * 16;
-    gather_edges_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(edges, idx, n_rows, N, K, C, out);
+    { tm_prof_begin("gather_edges", st); gather_edges_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(edges, idx, n_rows, N, K, C, out); tm_prof_end(st); }
     return tm_check_launch("gather_edges");
 }

@@ -189,18 +189,18 @@ int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const 
     HeadArgs a{w->conv_center, w->conv_b, w->mlp_w[0], w->mlp_b[0], w->mlp_w[1], w->mlp_b[1], w->mlp_w[2], w->mlp_b[2],
                w->ddg_w, w->ddg_b, w->Ws_w, hA, hB, S, ddg, z_opt, (int)T};
     const int64_t tiles = (T + TM_TILE - 1) / TM_TILE, cap = tm_num_cus();
-    head_kernel<<<(int)(tiles < cap ? tiles : cap), TM_THREADS, 0, st>>>(a);
+    { tm_prof_begin("head", st); head_kernel<<<(int)(tiles < cap ? tiles : cap), TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
     return tm_check_launch("ddg_head");
 }
 
 int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, hipStream_t st) {
     const int64_t blocks = (T + 3) / 4, cap = (int64_t)tm_num_cus() * 8;
-    log_probs_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Wout_w, w->Wout_b, h, (int)T, out);
+    { tm_prof_begin("log_probs", st); log_probs_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Wout_w, w->Wout_b, h, (int)T, out); tm_prof_end(st); }
     return tm_check_launch("log_probs");
 }
 
 int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float *hS, hipStream_t st) {
     const int64_t blocks = (T * 32 + TM_THREADS - 1) / TM_THREADS, cap = (int64_t)tm_num_cus() * 8;
-    seq_embed_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Ws_w, S, T, hS);
+    { tm_prof_begin("seq_embed", st); seq_embed_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Ws_w, S, T, hS); tm_prof_end(st); }
     return tm_check_launch("seq_embed");
 }

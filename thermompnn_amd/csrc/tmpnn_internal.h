@@ -40,6 +40,8 @@ struct LayerWs {
 
 int tm_set_error(int code, const char *fmt, ...);
 int tm_check_launch(const char *what);
+void tm_prof_begin(const char *name, hipStream_t st);   // no-ops unless tmpnn_profile_enable(1)
+void tm_prof_end(hipStream_t st);
 
 // tmpnn_graph.hip
 int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,

@@ -391,7 +391,7 @@ static int grid_for(int64_t work_items, int blocks_per_cu) {
 int launch_node_proj(const float *h, const float *Wa, int lda, const float *ba, const float *Wc, int ldc, int64_t T,
                      float *P, hipStream_t st) {
     const int64_t tiles = (T + TM_TILE - 1) / TM_TILE;
-    node_proj_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(h, Wa, lda, ba, Wc, ldc, (int)T, P);
+    { tm_prof_begin("node_proj", st); node_proj_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(h, Wa, lda, ba, Wc, ldc, (int)T, P); tm_prof_end(st); }
     return tm_check_launch("node_proj");
 }
 
@@ -400,14 +400,14 @@ int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float
                int64_t T, float *Ssum, float *cnt, hipStream_t st) {
     MsgArgs a{W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, Ssum, cnt, (int)T};
     const int grid = grid_for(T, 2);
-    if (dec) msg_kernel<true><<<grid, TM_THREADS, 0, st>>>(a);
-    else msg_kernel<false><<<grid, TM_THREADS, 0, st>>>(a);
+    if (dec) { tm_prof_begin("dec_msg", st); msg_kernel<true><<<grid, TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
+    else { tm_prof_begin("enc_msg", st); msg_kernel<false><<<grid, TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
     return tm_check_launch(dec ? "dec_msg" : "enc_msg");
 }
 
 int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
     EdgeArgs a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
-    enc_edge_kernel<<<grid_for(T, 1), TM_THREADS, 0, st>>>(a);
+    { tm_prof_begin("enc_edge", st); enc_edge_kernel<<<grid_for(T, 1), TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
     return tm_check_launch("enc_edge");
 }
 
@@ -417,6 +417,6 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
                        float *h_out, hipStream_t st) {
     NodeArgs a{W3, b3, n1w, n1b, Win, bin, Wout, bout, n2w, n2b, h_in, Ssum, cnt, mask, h_out, (int)T};
     const int64_t tiles = (T + TM_TILE - 1) / TM_TILE;
-    node_update_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a);
+    { tm_prof_begin("node_update", st); node_update_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
     return tm_check_launch("node_update");
 }
