@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--length", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="timed workload only (no gather microbench / single-protein leg / cpu baseline): use under rocprofv3")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -223,6 +225,7 @@ def main():
                                   "tflops_end_to_end": total_fl / (dt / args.steps) / 1e12,
                                   "frac_of_fp32_mfma_peak": total_fl / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                   "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in kern.values()) / args.steps}
+    if rank == 0 and not args.no_extras:
         result["roofline_gather"] = gather_microbench(eng, device)
         # single-protein latency (the literal configs[1]): B = 1
         one = build_batch(1, L, 0, device)
@@ -239,6 +242,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(batch)
             result["cpu_baseline"]["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+    if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
