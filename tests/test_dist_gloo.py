@@ -1,0 +1,82 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the sharding + ragged all-gather (no GPU compute)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from thermompnn_amd.dist import all_gather_tables, partition_proteins, scan_sharded
+
+
+def fake_table(pid, L):
+    """Deterministic stand-in for a protein's ddG table (the collective logic does not care about the values)."""
+    r = np.random.default_rng(1000 + pid)
+    return torch.tensor(r.normal(size=(L, 21)), dtype=torch.float32)
+
+
+def _worker(rank, world, port, lengths, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seen = []
+
+        def compute(ids):
+            seen.extend(ids)
+            return torch.cat([fake_table(i, lengths[i]) for i in ids]) if ids else torch.zeros((0, 21))
+
+        tables = scan_sharded(lengths, compute)
+        ok = all(torch.equal(t, fake_table(i, lengths[i])) for i, t in enumerate(tables))
+        # ragged gather incl. an empty shard
+        rows = [3, 0] if world == 2 else [1] * world
+        got = all_gather_tables(torch.full((rows[rank], 2), float(rank)), rows)
+        ok = ok and [g.shape[0] for g in got] == rows and all((g == r).all() for r, g in enumerate(got))
+        q.put((rank, ok, sorted(seen)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_scan_gloo(world):
+    lengths = [int(x) for x in np.random.default_rng(2).integers(40, 73, size=11)] + [300, 5]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in results)
+    seen = sorted(i for _, _, ids in results for i in ids)
+    assert seen == list(range(len(lengths)))                      # every protein computed exactly once
+    shards = partition_proteins(lengths, world)
+    assert [sorted(ids) for _, _, ids in sorted(results)] == shards
+
+
+def test_partition_is_balanced_and_deterministic():
+    lengths = [int(x) for x in np.random.default_rng(1).integers(64, 513, size=1024)]   # BASELINE config 3
+    for world in (1, 2, 4, 8):
+        shards = partition_proteins(lengths, world)
+        assert sorted(i for s in shards for i in s) == list(range(1024))
+        load = [sum(lengths[i] * min(48, lengths[i]) for i in s) for s in shards]
+        assert max(load) - min(load) <= 512 * 48                  # LPT: within one largest item
+        assert shards == partition_proteins(lengths, world)
+    short = partition_proteins([10, 20, 30], 8)                   # more ranks than proteins
+    assert sum(len(s) for s in short) == 3 and len(short) == 8
+
+
+def test_single_process_scan_needs_no_group():
+    lengths = [7, 3, 9]
+    tables = scan_sharded(lengths, lambda ids: torch.cat([fake_table(i, lengths[i]) for i in ids]))
+    assert all(torch.equal(t, fake_table(i, L)) for i, (t, L) in enumerate(zip(tables, lengths)))

@@ -349,3 +349,37 @@ def test_large_chain_vs_oracle(engine, synthetic_weights):
         want = orc.ssm_table(synthetic_weights, X[None], S[None], ones, ones, ar, ones.long(), 48)[0].numpy()
     r = engine.ssm_forward(X, S.int(), torch.ones(L), torch.arange(L), torch.ones(L), torch.tensor([0, L], dtype=torch.int32))
     np.testing.assert_allclose(r["ddg"].cpu().numpy(), want, atol=TOL_DDG, rtol=0)
+
+
+def test_custom_inference_script_end_to_end(tmp_path):
+    """BASELINE config 1 counterpart: PDB -> CSV with the reference schema, values vs the reference golden."""
+    import csv
+    from thermompnn_amd import custom_inference
+    out = custom_inference.main(["--pdb", os.path.join(GOLDEN, "2OCJ.pdb"), "--chain", "A", "--synthetic_weights", "0",
+                                 "--out_dir", str(tmp_path)])
+    assert os.path.basename(out) == "ThermoMPNN_inference_2OCJ.csv"
+    rows = list(csv.DictReader(open(out)))
+    g = load_golden("2OCJ_A")
+    assert len(rows) == 3880 and list(rows[0].keys()) == ["", "Model", "Dataset", "ddG_pred", "position", "wildtype", "mutation", "pdb", "chain"]
+    for r in rows[::97]:
+        want = g["ddg"][int(r["position"]), "ACDEFGHIKLMNPQRSTVWY".index(r["mutation"])]
+        assert abs(float(r["ddG_pred"]) - want) <= TOL_DDG
+        assert r["pdb"] == "2OCJ" and r["chain"] == "A" and r["Model"] == "ThermoMPNN"
+
+
+def test_sharded_scan_single_rank_ragged(engine):
+    """dist.ssm_scan on one rank over a config-4-like ragged set (L in [40, 72], K_eff = min(48, L))."""
+    from thermompnn_amd.dist import ssm_scan
+    from thermompnn_amd.synthetic import synthetic_backbone
+    rng = np.random.default_rng(2)
+    prots = []
+    for i, L in enumerate(rng.integers(40, 73, size=12)):
+        X, seq = synthetic_backbone(int(L), 500 + i)
+        prots.append(dict(X=X.astype(np.float32), S=np.array(["ACDEFGHIKLMNPQRSTVWY".index(c) for c in seq], dtype=np.int32),
+                          mask=np.ones(L, np.float32), residue_idx=np.arange(L, dtype=np.int32), chain_enc=np.ones(L, np.int32)))
+    tables = ssm_scan(engine, prots)
+    assert [t.shape for t in tables] == [(len(p["S"]), 21) for p in prots]
+    p = prots[5]
+    L = len(p["S"])
+    single = engine.ssm_forward(p["X"], p["S"], p["mask"], p["residue_idx"], p["chain_enc"], torch.tensor([0, L], dtype=torch.int32))["ddg"]
+    assert torch.equal(tables[5], single)

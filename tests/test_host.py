@@ -111,3 +111,14 @@ def test_weight_formats_roundtrip(tmp_path):
     assert list(back) == list(sd) and all(torch.equal(back[n], sd[n]) for n in sd)
     assert torch.equal(weights.synthetic_state_dict(3)["both_out.1.weight"], sd["both_out.1.weight"])
     assert (sd["light_attention.feature_convolution.weight"] != 0).all()
+
+
+def test_csv_writer_schema(tmp_path):
+    from thermompnn_amd.custom_inference import first_chain, pdb_id_of, write_csv
+    rows = [{"Model": "ThermoMPNN", "Dataset": "2OCJ", "ddG_pred": -0.25, "position": 0, "wildtype": "S",
+             "mutation": "A", "pdb": "2OCJ", "chain": "A"}]
+    write_csv(rows, tmp_path / "o.csv")
+    lines = (tmp_path / "o.csv").read_text().splitlines()
+    assert lines[0] == ",Model,Dataset,ddG_pred,position,wildtype,mutation,pdb,chain"     # examples/ThermoMPNN_inference_2OCJ.csv:1
+    assert lines[1] == "0,ThermoMPNN,2OCJ,-0.25,0,S,A,2OCJ,A"
+    assert pdb_id_of("/x/y/2OCJ.pdb") == "2OCJ" and first_chain(PDB) == "A"
