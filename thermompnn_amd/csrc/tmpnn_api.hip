@@ -363,6 +363,13 @@ extern "C" int tmpnn_enc_layer(const tmpnn_weights_t *w, int layer, float *h_V, 
     return run_enc_layer(w, layer, h_V, h_E, E_idx, mask, T, ws, (hipStream_t)stream);
 }
 
+// measurement hook (tools/ablate.py): the encoder edge-update kernel alone, with parts switched off
+extern "C" int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const float *P, float *h_E, const int32_t *E_idx,
+                                     int64_t T, int ablation, tmpnn_stream_t stream) {
+    REQUIRE(w && P && h_E && E_idx && layer >= 0 && layer < 3 && T > 0 && T <= T_MAX, "ablate_enc_edge: bad argument");
+    return launch_enc_edge(w->enc[layer], P, h_E, E_idx, T, (hipStream_t)stream, ablation);
+}
+
 extern "C" int tmpnn_dec_layer(const tmpnn_weights_t *w, int layer, const float *h_V_in, float *h_V_out, const float *h_E,
                                const int32_t *E_idx, const int32_t *S, const float *mask, int64_t T, void *workspace,
                                size_t workspace_bytes, tmpnn_stream_t stream) {
