@@ -62,7 +62,10 @@ class Weights:
     def __del__(self):
         h = getattr(self, "handle", None)
         if h is not None and h.value:
-            _lib.load().tmpnn_weights_destroy(h)
+            try:
+                _lib.load().tmpnn_weights_destroy(h)
+            except Exception:      # interpreter shutdown: the library may already be gone
+                pass
             self.handle = None
 
 
