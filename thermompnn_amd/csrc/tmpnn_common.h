@@ -26,6 +26,21 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Persistent-kernel work split that is XCD-aware: workgroup b is observed to run on XCD b % 8 (placement is a
+// speed hint only, never relied on for correctness). Giving each XCD one CONTIGUOUS eighth of the packed
+// residue axis keeps the rows its tiles gather (neighbours live in the same protein) inside that XCD's 4 MB L2
+// instead of bouncing the whole [T,256] projection table through every L2 (MI355X_MICROARCH.md: per-XCD L2).
+struct TileRange { int begin, end, step; };
+__device__ __forceinline__ TileRange xcd_tile_range(int n_tiles) {
+    const int G = gridDim.x, b = blockIdx.x;
+    if ((G & 7) == 0 && n_tiles >= 8 * G) {
+        const int x = b & 7, lb = b >> 3;
+        const int s = (int)((long long)n_tiles * x / 8), e = (int)((long long)n_tiles * (x + 1) / 8);
+        return TileRange{s + lb, e, G >> 3};
+    }
+    return TileRange{b, n_tiles, G};
+}
+
 // float offset of 16-byte chunk `c` of row `m` in a swizzled tile whose rows are RS floats long
 template <int RS = 128>
 __device__ __forceinline__ int chunk_off(int m, int c) { return m * RS + ((c ^ (m & 15)) << 2); }

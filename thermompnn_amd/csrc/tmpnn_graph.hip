@@ -153,7 +153,8 @@ __global__ __launch_bounds__(TM_THREADS, 1) void featurize_kernel(FeatArgs a) {
     }
     const f4 g4 = ld4(a.ln_w + 4 * c32), b4 = ld4(a.ln_b + 4 * c32);
 
-    for (int i = blockIdx.x; i < a.T; i += gridDim.x) {
+    const TileRange tr = xcd_tile_range(a.T);
+    for (int i = tr.begin; i < tr.end; i += tr.step) {
         if (tid < TM_TILE) {
             const int j = a.E_idx[(size_t)i * TM_KS + tid];
             s_idx[tid] = j;
@@ -256,8 +257,17 @@ __global__ __launch_bounds__(TM_THREADS) void gather_rows_kernel(const float *__
                                                                  int64_t rows_per_batch, int64_t nodes_per_batch,
                                                                  int C4, float *__restrict__ out) {
     const int64_t total = n_rows * C4;
-    const int64_t stride = (int64_t)gridDim.x * TM_THREADS;
-    for (int64_t g = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x; g < total; g += stride) {
+    // XCD-aware split (see xcd_tile_range): each XCD streams one contiguous eighth of the output, so the table
+    // rows it gathers (neighbours are local) stay in its own L2
+    int64_t g0 = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x, g1 = total, stride = (int64_t)gridDim.x * TM_THREADS;
+    if ((gridDim.x & 7) == 0 && total >= 8 * stride) {
+        const int x = blockIdx.x & 7;
+        const int64_t s = total / 8 * x;
+        g1 = x == 7 ? total : total / 8 * (x + 1);
+        g0 = s + (int64_t)(blockIdx.x >> 3) * TM_THREADS + threadIdx.x;
+        stride >>= 3;
+    }
+    for (int64_t g = g0; g < g1; g += stride) {
         const int64_t r = g / C4;
         const int c = (int)(g - r * C4);
         const int64_t j = (int64_t)idx[r];

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(TM_THREADS, 2) void msg_kernel(MsgArgs a) {
         bias2[cb] = ld4(a.b2 + n0 + 4 * q);
     }
 
-    for (int i = blockIdx.x; i < a.T; i += gridDim.x) {
+    const TileRange tr = xcd_tile_range(a.T);
+    for (int i = tr.begin; i < tr.end; i += tr.step) {
         const float mi = a.mask[i];
         if (tid < TM_TILE) {
             const int j = a.E_idx[(size_t)i * TM_KS + tid];
@@ -255,10 +256,11 @@ __global__ __launch_bounds__(TM_THREADS, 1) void enc_edge_kernel(EdgeArgs a) {
     const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
     const int ncol = 32 * wv + 4 * q;                     // this lane's first column (block 0); block 1 = +16
 
-    int i = blockIdx.x;
+    const TileRange tr = xcd_tile_range(a.T);
+    int i = tr.begin;
     int cur = 0;
     f4 gai[2], gcj[3][2];                                 // A'_i and C'_j rows of the tile about to be processed
-    if (i < a.T) {                                        // prologue: first tile
+    if (i < tr.end) {                                     // prologue: first tile
         if (tid < TM_TILE) s_idx[0][tid] = a.E_idx[(size_t)i * TM_KS + tid];
         if (!(ABL & 1)) load_tile_async(tE[0], a.hE + (size_t)i * TM_KS * TM_H, wv, lane);
         __syncthreads();
@@ -273,11 +275,11 @@ __global__ __launch_bounds__(TM_THREADS, 1) void enc_edge_kernel(EdgeArgs a) {
         }
     }
 
-    for (; i < a.T; i += gridDim.x) {
+    for (; i < tr.end; i += tr.step) {
         float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
         const float *tEc = tE[cur];
-        const int inext = i + gridDim.x;
-        const bool has_next = inext < a.T;
+        const int inext = i + tr.step;
+        const bool has_next = inext < tr.end;
         int nidx = -1;
         if (has_next) {
             if (!(ABL & 1)) load_tile_async(tE[cur ^ 1], a.hE + (size_t)inext * TM_KS * TM_H, wv, lane);
