@@ -47,6 +47,18 @@ def kernel_flops(name, T, edges):
     }.get(name)
 
 
+def pmc_traffic(kernel, T):
+    """HBM bytes per launch from the rocprofv3 --pmc passes committed under profiles/ (collected separately with
+    tools/pmc_workload.py at T = 16384, gfx950 FETCH_SIZE correction applied); None if not applicable."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    if T != 16384 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["kernels"].get(kernel, {}).get("traffic_bytes")
+    except Exception:
+        return None
+
+
 def build_batch(n_proteins, L, seed0, device):
     xs, ss = [], []
     for i in range(n_proteins):
@@ -212,7 +224,8 @@ def main():
             fl = kernel_flops(dom, T, edges)
             achieved = fl / (kern[dom]["avg_ms"] * 1e-3) / 1e12
             result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": dom,
+                                  "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom, T), "kernel": dom,
+                                  "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_traffic.json)",
                                   "flops_per_launch": fl, "avg_launch_ms": kern[dom]["avg_ms"],
                                   "timed_with": "hipEvent pairs on the launch stream inside the timed region"}
             for k, v in kern.items():
@@ -227,6 +240,7 @@ def main():
                                   "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in kern.values()) / args.steps}
     if rank == 0 and not args.no_extras:
         result["roofline_gather"] = gather_microbench(eng, device)
+        result["roofline_gather"]["traffic"] = pmc_traffic("gather_rows", 16384)
         # single-protein latency (the literal configs[1]): B = 1
         one = build_batch(1, L, 0, device)
         o1 = {"ddg": torch.empty((L, 21), dtype=torch.float32, device=device)}
