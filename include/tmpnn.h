@@ -160,6 +160,11 @@ int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const float *P, f
                           int64_t T, int ablation, tmpnn_stream_t stream);
 int tmpnn_profile_fetch(const char **names, double *total_ms, int64_t *launches, int capacity);
 
+/* Effective shader clock under a saturated fp32-MFMA stream (192 v_mfma_f32_16x16x4_f32 per iteration per wavefront,
+ * 4 wavefronts per workgroup): out[2b] = shader cycles of workgroup b, out[2b+1] = the same interval in 100 MHz ticks.
+ * `sink` (>= 256 floats) keeps the result live. */
+int tmpnn_clock_probe(int blocks, int iters, uint64_t *out, float *sink, tmpnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -383,3 +383,28 @@ def test_sharded_scan_single_rank_ragged(engine):
     L = len(p["S"])
     single = engine.ssm_forward(p["X"], p["S"], p["mask"], p["residue_idx"], p["chain_enc"], torch.tensor([0, L], dtype=torch.int32))["ddg"]
     assert torch.equal(tables[5], single)
+
+
+def test_enc_edge_kernel_variants_agree(engine):
+    """The experimental edge-update kernels (ping-pong, 8-wavefront, 2-workgroups-per-CU; selectable through the
+    measurement hook tmpnn_ablate_enc_edge) compute the same function as the shipped kernel."""
+    from thermompnn_amd import _lib
+    from thermompnn_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    T = 777                                                    # not a multiple of anything: odd tile counts per workgroup
+    g = torch.Generator().manual_seed(3)
+    P = torch.randn(T, 256, generator=g).cuda()
+    hE = torch.randn(T, 48, 128, generator=g).cuda()
+    E_idx = torch.randint(0, T, (T, 48), generator=g).int()
+    E_idx[5, 40:] = -1                                         # invalid slots keep their (zero) rows
+    E_idx = E_idx.cuda()
+    hE[5, 40:] = 0
+    outs = {}
+    for code in (0, 16, 32, 64):
+        x = hE.clone()
+        assert lib.tmpnn_ablate_enc_edge(engine.w.handle, 1, _ptr(P), _ptr(x), _ptr(E_idx), T, code, _stream()) == 0
+        torch.cuda.synchronize()
+        outs[code] = x.cpu()
+    assert torch.equal(outs[0], outs[16]) and torch.equal(outs[0], outs[64])
+    assert (outs[0] - outs[32]).abs().max() < 1e-5             # different LayerNorm-statistics merge order
+    assert (outs[0][5, 40:] == 0).all()

@@ -43,6 +43,7 @@ SIGNATURES = {
     "tmpnn_log_probs": (_i, [_p, _p, _i64, _p, _p]),
     "tmpnn_ddg_head": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p]),
     "tmpnn_profile_enable": (_i, [_i]),
+    "tmpnn_clock_probe": (_i, [_i, _i, _p, _p, _p]),
     "tmpnn_ablate_enc_edge": (_i, [_p, _i, _p, _p, _p, _i64, _i, _p]),
     "tmpnn_profile_fetch": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), _i]),
     "tmpnn_ssm_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),

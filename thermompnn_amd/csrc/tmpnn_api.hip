@@ -370,6 +370,12 @@ extern "C" int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const 
     return launch_enc_edge(w->enc[layer], P, h_E, E_idx, T, (hipStream_t)stream, ablation);
 }
 
+// measurement hook: effective shader clock under a saturated fp32-MFMA load; out[2b] = shader cycles, out[2b+1] = 100 MHz ticks
+extern "C" int tmpnn_clock_probe(int blocks, int iters, uint64_t *out, float *sink, tmpnn_stream_t stream) {
+    REQUIRE(blocks > 0 && iters > 0 && out && sink, "clock_probe: bad argument");
+    return launch_clock_probe(blocks, iters, (unsigned long long *)out, sink, (hipStream_t)stream);
+}
+
 extern "C" int tmpnn_dec_layer(const tmpnn_weights_t *w, int layer, const float *h_V_in, float *h_V_out, const float *h_E,
                                const int32_t *E_idx, const int32_t *S, const float *mask, int64_t T, void *workspace,
                                size_t workspace_bytes, tmpnn_stream_t stream) {

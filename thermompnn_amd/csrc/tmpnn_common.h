@@ -19,6 +19,9 @@
 #define TM_KS 48
 #define TM_TILE 48
 #define TM_THREADS 256
+#ifndef TM_SCHED_FILL
+#define TM_SCHED_FILL 4
+#endif
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -109,6 +112,48 @@ __device__ __forceinline__ void mma_tile(const float *tile, const float (&w)[NCB
     }
 }
 
+// Same GEMM with a slice of unrelated VALU / LDS / global work issued inside every 16-deep k-step (`slice(kk)`,
+// kk a compile-time constant after unrolling). The work in `slice` must be independent of `acc`; the matrix pipe
+// and the VALU are separate, so the hardware overlaps the two streams when they are interleaved in program
+// order. B fragments are fetched one k-step ahead.
+template <int NK16, int NCB, int RS = 128, typename F>
+__device__ __forceinline__ void mma_tile_with(const float *tile, const float (&w)[NCB][NK16 * 4], f4 (&acc)[3][NCB],
+                                              int lane, F &&slice) {
+    const int m = lane & 15, q = lane >> 4;
+    f4 a[3];
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb) a[rb] = ld4(tile + chunk_off<RS>(16 * rb + m, q));
+#pragma unroll
+    for (int kk = 0; kk < NK16; ++kk) {
+        f4 an[3];
+        if (kk + 1 < NK16) {
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) an[rb] = ld4(tile + chunk_off<RS>(16 * rb + m, 4 * (kk + 1) + q));
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma16(w[cb][4 * kk + s], a[rb][s], acc[rb][cb]);
+        slice(kk);
+        if (kk + 1 < NK16) {
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) a[rb] = an[rb];
+        }
+#if TM_SCHED_FILL > 0
+        // pin an even interleave: after every MFMA at most TM_SCHED_FILL non-matrix instructions (VALU | SALU | VMEM |
+        // DS | TRANS). One wavefront per SIMD issues roughly one instruction per 4 cycles, so a 32-cycle
+        // v_mfma_f32_16x16x4_f32 hides about five of them (MI355X_MICROARCH.md, per-instruction constants).
+#pragma unroll
+        for (int g = 0; g < 12 * NCB; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x496, TM_SCHED_FILL, 0);
+        }
+#endif
+    }
+}
+
 // Cooperative load of a contiguous [48,128] fp32 block from global into a swizzled LDS tile
 // (coalesced 16-byte loads; 6 per thread). rows_valid < 48 zero-fills the tail rows.
 __device__ __forceinline__ void load_tile(float *tile, const float *__restrict__ src, int rows_valid, int tid) {
@@ -126,10 +171,11 @@ __device__ __forceinline__ void load_tile(float *tile, const float *__restrict__
 // XOR swizzle is applied on the per-lane SOURCE address (cdna_hip_programming.md rule 21) — a permutation
 // inside the row's 512 B, so the global access stays fully coalesced. Each wavefront issues 6 instructions.
 // The data is visible after the next __syncthreads() (hipcc drains vmcnt before the barrier).
+template <int NW = 4>   // wavefronts per workgroup sharing the 24 row-pair instructions
 __device__ __forceinline__ void load_tile_async(float *tile, const float *__restrict__ src, int wv, int lane) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int rp = 6 * wv + k;                        // row pair
+    for (int k = 0; k < 24 / NW; ++k) {
+        const int rp = (24 / NW) * wv + k;                // row pair
         const int row = 2 * rp + (lane >> 5);
         const int c = (lane & 31) ^ (row & 15);           // logical chunk that belongs at physical slot (lane & 31)
         __builtin_amdgcn_global_load_lds(

@@ -71,4 +71,5 @@ int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *o
 int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float *hS, hipStream_t st);
 int launch_prep_tables(tmpnn_weights *w, hipStream_t st);
 
+int launch_clock_probe(int blocks, int iters, unsigned long long *out, float *sink, hipStream_t st);
 int tm_num_cus();

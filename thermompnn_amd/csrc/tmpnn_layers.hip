@@ -10,6 +10,8 @@
 // the weight slices resident in VGPRs for the whole kernel and the residue's 48-slot neighbour list +
 // edge tile staged in LDS. Per-node aggregation over K is an in-workgroup column reduction
 // (deterministic; no atomics).
+#include <stdlib.h>
+
 #include "tmpnn_common.h"
 #include "tmpnn_internal.h"
 
@@ -76,6 +78,7 @@ struct MsgArgs {
     const float *mask;       // [T]
     float *Ssum, *cnt;
     int T;
+    int skew;                // start delay of the second half of the grid, in units of 64 cycles
 };
 
 template <bool DEC>
@@ -97,6 +100,12 @@ __global__ __launch_bounds__(TM_THREADS, 2) void msg_kernel(MsgArgs a) {
         bias2[cb] = ld4(a.b2 + n0 + 4 * q);
     }
 
+    // Two workgroups share every CU. A wavefront cannot overlap its own MFMAs with its own VALU work (measured,
+    // tools/probe/overlap_probe.hip: the costs add), but two wavefronts on one SIMD do overlap — provided they are in
+    // DIFFERENT phases. Identical workgroups started together stay phase-locked, so the second half of the grid
+    // starts a fraction of a tile period late (a.skew x 64 cycles).
+    if (a.skew > 0 && blockIdx.x >= (gridDim.x >> 1))
+        for (int k = 0; k < a.skew; k += 100) __builtin_amdgcn_s_sleep(100);
     const TileRange tr = xcd_tile_range(a.T);
     for (int i = tr.begin; i < tr.end; i += tr.step) {
         const float mi = a.mask[i];
@@ -358,6 +367,423 @@ __global__ __launch_bounds__(TM_THREADS, 1) void enc_edge_kernel(EdgeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// enc_edge, two-workgroups-per-CU form: same arithmetic as enc_edge_kernel<0>, trimmed to <= 256 VGPRs (192 of them
+// weights) and 74 KB of LDS so that TWO workgroups share a CU and one's GELU / LayerNorm / load phases run under the
+// other's GEMMs (cross-wavefront MFMA/VALU overlap works, same-wavefront does not: tools/probe/overlap_probe.hip).
+// No register prefetch: biases, LayerNorm parameters and gathered rows are (re)loaded at their point of use.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TM_THREADS, 2) void enc_edge2_kernel(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float tE[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][8];
+    __shared__ int s_idx[TM_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+
+    float w11[2][32], w12[2][32], w13[2][32];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int n0 = 32 * wv + 16 * cb;
+        load_wfrag<8>(a.W11e, 384, n0, 0, TM_H, w11[cb], lane);
+        load_wfrag<8>(a.W12, TM_H, n0, 0, TM_H, w12[cb], lane);
+        load_wfrag<8>(a.W13, TM_H, n0, 0, TM_H, w13[cb], lane);
+    }
+    const int c32 = lane & 31;
+    const int ncol = 32 * wv + 4 * q;
+
+    const TileRange tr = xcd_tile_range(a.T);
+    for (int i = tr.begin; i < tr.end; i += tr.step) {
+        float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
+        if (tid < TM_TILE) s_idx[tid] = a.E_idx[(size_t)i * TM_KS + tid];
+        load_tile_async(tE, tile_g, wv, lane);
+        __syncthreads();
+
+        f4 acc[3][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const f4 ai = ld4(a.P + (size_t)i * 256 + ncol + 16 * cb);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                const int j = s_idx[16 * rb + m];
+                acc[rb][cb] = ai + ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol + 16 * cb);
+            }
+        }
+        mma_tile<8, 2>(tE, w11, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) st4(tA + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(acc[rb][cb]));
+        __syncthreads();
+
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const f4 b = ld4(a.b12 + ncol + 16 * cb);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = b;
+        }
+        mma_tile<8, 2>(tA, w12, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) st4(tB + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(acc[rb][cb]));
+        __syncthreads();
+
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const f4 b = ld4(a.b13 + ncol + 16 * cb);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = b;
+        }
+        mma_tile<8, 2>(tB, w13, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            f4 v[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int off = chunk_off(16 * rb + m, 8 * wv + 4 * cb + q);
+                v[cb] = ld4(tE + off) + acc[rb][cb];
+                st4(tA + off, v[cb]);
+            }
+            row_stats_partial(v, &s_stat[16 * rb + m][2 * wv], q);
+        }
+        __syncthreads();
+
+        {
+            const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int row = 12 * wv + 2 * it + (lane >> 5);
+                float mean, rstd;
+                row_stats_finish(&s_stat[row][0], mean, rstd);
+                const f4 y = (ld4(tA + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
+                if (s_idx[row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// enc_edge, 8-wavefront form: 512 threads, wavefront w owns ONE 16-column block (96 weight VGPRs instead of 192), so
+// two wavefronts share each SIMD: the matrix pipe sees the same 192 MFMAs per GEMM per SIMD, but their issue, the
+// LDS waits and above all the VALU phases (GELU, LayerNorm) interleave between two instruction streams — a single
+// wavefront issues only about one instruction every 4-5 cycles (MI355X_MICROARCH.md, per-instruction constants).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void row_stats_partial1(const f4 v, float *stat_slot, int q) {
+    float mean = (v.x + v.y + v.z + v.w) * 0.25f;
+    const f4 d = v - mean;
+    float m2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    float n = 4.f;
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float mo = __shfl_xor(mean, off), m2o = __shfl_xor(m2, off);
+        const float delta = mo - mean;
+        mean = 0.5f * (mean + mo);
+        m2 = m2 + m2o + delta * delta * (0.5f * n);
+        n *= 2.f;
+    }
+    if (q == 0) { stat_slot[0] = mean; stat_slot[1] = m2; }
+}
+// merge eight per-wavefront (mean, M2) partials of 16 columns each
+__device__ __forceinline__ void row_stats_finish8(const float *stat_row /* 16 floats */, float &mean, float &rstd) {
+    f4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = ld4(stat_row + 4 * k);
+    mean = 0.125f * (p[0].x + p[0].z + p[1].x + p[1].z + p[2].x + p[2].z + p[3].x + p[3].z);
+    float m2 = 0.f, dd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float d0 = p[k].x - mean, d1 = p[k].z - mean;
+        m2 += p[k].y + p[k].w;
+        dd += d0 * d0 + d1 * d1;
+    }
+    rstd = 1.0f / sqrtf((m2 + 16.f * dd) * (1.0f / 128.0f) + 1e-5f);
+}
+
+__global__ __launch_bounds__(512, 2) void enc_edge8_kernel(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float tE[2][TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
+    __shared__ int s_idx[2][TM_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+
+    float w11[1][32], w12[1][32], w13[1][32];
+    load_wfrag<8>(a.W11e, 384, 16 * wv, 0, TM_H, w11[0], lane);
+    load_wfrag<8>(a.W12, TM_H, 16 * wv, 0, TM_H, w12[0], lane);
+    load_wfrag<8>(a.W13, TM_H, 16 * wv, 0, TM_H, w13[0], lane);
+    const int ncol = 16 * wv + 4 * q, chunk = 4 * wv + q;
+    const f4 b12 = ld4(a.b12 + ncol), b13 = ld4(a.b13 + ncol);
+    const int c32 = lane & 31;
+    const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
+
+    const TileRange tr = xcd_tile_range(a.T);
+    int i = tr.begin;
+    int cur = 0;
+    f4 gai, gcj[3];
+    if (i < tr.end) {
+        if (tid < TM_TILE) s_idx[0][tid] = a.E_idx[(size_t)i * TM_KS + tid];
+        load_tile_async<8>(tE[0], a.hE + (size_t)i * TM_KS * TM_H, wv, lane);
+        __syncthreads();
+        gai = ld4(a.P + (size_t)i * 256 + ncol);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int j = s_idx[0][16 * rb + m];
+            gcj[rb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol);
+        }
+    }
+    for (; i < tr.end; i += tr.step) {
+        float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
+        const float *tEc = tE[cur];
+        const int inext = i + tr.step;
+        const bool has_next = inext < tr.end;
+        int nidx = -1;
+        if (has_next) {
+            load_tile_async<8>(tE[cur ^ 1], a.hE + (size_t)inext * TM_KS * TM_H, wv, lane);
+            if (tid < TM_TILE) nidx = a.E_idx[(size_t)inext * TM_KS + tid];
+        }
+        f4 acc[3][1];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
+        mma_tile<8, 1>(tEc, w11, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) st4(tA + chunk_off(16 * rb + m, chunk), gelu4(acc[rb][0]));
+        if (has_next && tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx;
+        __syncthreads();
+
+        if (has_next) {
+            gai = ld4(a.P + (size_t)inext * 256 + ncol);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                const int j = s_idx[cur ^ 1][16 * rb + m];
+                gcj[rb] = ld4(a.P + (size_t)(j < 0 ? inext : j) * 256 + 128 + ncol);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
+        mma_tile<8, 1>(tA, w12, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) st4(tB + chunk_off(16 * rb + m, chunk), gelu4(acc[rb][0]));
+        __syncthreads();
+
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
+        mma_tile<8, 1>(tB, w13, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int off = chunk_off(16 * rb + m, chunk);
+            const f4 v = ld4(tEc + off) + acc[rb][0];          // residual
+            st4(tA + off, v);
+            row_stats_partial1(v, &s_stat[16 * rb + m][2 * wv], q);
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int row = 6 * wv + 2 * it + (lane >> 5);
+            float mean, rstd;
+            row_stats_finish8(&s_stat[row][0], mean, rstd);
+            const f4 y = (ld4(tA + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
+            if (s_idx[cur][row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// enc_edge, ping-pong form: TWO residues (streams A and B) are in flight per workgroup, skewed by one stage, so
+// every barrier interval pairs a GEMM of one tile (matrix pipe) with the GELU / residual / LayerNorm-store work
+// of the other (VALU, LDS, global stores), interleaved at k-step granularity by mma_tile_with():
+//     J1 V1(A)|M1(B)  J2 M2(A)|V1(B)  J3 V2(A)|M2(B)  J4 M3(A)|V2(B)  J5 V3(A)|M3(B)  J6 S(A),V3(B)  J7 M1(A')|S(B)
+// Each tile owns three LDS buffers (e, x, y); the next tile of a stream is DMA-ed into the y buffer as soon as
+// its GEMM3 has consumed it and the roles rotate (e,x,y) <- (y,x,e). 6 x 24 KB of LDS, 7 barriers per pair.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TM_THREADS, 1) void enc_edge_pp_kernel(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float tiles[6][TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float s_stat[2][TM_TILE][8];
+    __shared__ int s_idx[2][2][TM_TILE];                       // [stream][parity][slot]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+
+    float w11[2][32], w12[2][32], w13[2][32];
+    f4 b12[2], b13[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int n0 = 32 * wv + 16 * cb;
+        load_wfrag<8>(a.W11e, 384, n0, 0, TM_H, w11[cb], lane);
+        load_wfrag<8>(a.W12, TM_H, n0, 0, TM_H, w12[cb], lane);
+        load_wfrag<8>(a.W13, TM_H, n0, 0, TM_H, w13[cb], lane);
+        b12[cb] = ld4(a.b12 + n0 + 4 * q);
+        b13[cb] = ld4(a.b13 + n0 + 4 * q);
+    }
+    const int c32 = lane & 31;
+    const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
+    const int ncol = 32 * wv + 4 * q;
+
+    const TileRange tr = xcd_tile_range(a.T);
+    if (tr.begin >= tr.end) return;
+    const int n = (tr.end - tr.begin + tr.step - 1) / tr.step;   // tiles of this workgroup
+    const int npairs = (n + 1) >> 1;
+    auto tile_of = [&](int k) { return tr.begin + (k < n ? k : n - 1) * tr.step; };
+
+    int be[2] = {0, 3}, bx[2] = {1, 4}, by[2] = {2, 5};
+    int par = 0;
+    f4 gai[2][2], gcj[2][3][2];                                // [stream]: A'_i and C'_j rows (acc init of GEMM1)
+    f4 accA[3][2], accB[3][2];
+
+    auto gather = [&](int s, int i, int parity) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            gai[s][cb] = ld4(a.P + (size_t)i * 256 + ncol + 16 * cb);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                const int j = s_idx[s][parity][16 * rb + m];
+                gcj[s][rb][cb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol + 16 * cb);
+            }
+        }
+    };
+    // V1 / V2: block k of the GELU epilogue (k = 2 rb + cb)
+    auto gelu_block = [&](f4 (&acc)[3][2], float *dst, int k) {
+        if (k < 6) {
+            const int rb = k >> 1, cb = k & 1;
+            st4(dst + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(acc[rb][cb]));
+        }
+    };
+    // V3: residual + LayerNorm partial statistics of row block k
+    auto resid_block = [&](f4 (&acc)[3][2], const float *e, float *dst, int s, int k) {
+        if (k < 3) {
+            f4 v[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int off = chunk_off(16 * k + m, 8 * wv + 4 * cb + q);
+                v[cb] = ld4(e + off) + acc[k][cb];
+                st4(dst + off, v[cb]);
+            }
+            row_stats_partial(v, &s_stat[s][16 * k + m][2 * wv], q);
+        }
+    };
+    // S: normalise + store two rows (iteration k of 6)
+    auto store_rows = [&](const float *x, int s, int parity, float *tile_g, bool valid, int k) {
+        if (k < 6) {
+            const int row = 12 * wv + 2 * k + (lane >> 5);
+            float mean, rstd;
+            row_stats_finish(&s_stat[s][row][0], mean, rstd);
+            const f4 y = (ld4(x + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
+            if (valid && s_idx[s][parity][row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
+        }
+    };
+
+    // ---- prologue: first pair in, GEMM1 of A ----
+    {
+        const int iA = tile_of(0), iB = tile_of(1);
+        if (tid < TM_TILE) {
+            s_idx[0][0][tid] = a.E_idx[(size_t)iA * TM_KS + tid];
+            s_idx[1][0][tid] = a.E_idx[(size_t)iB * TM_KS + tid];
+        }
+        load_tile_async(tiles[be[0]], a.hE + (size_t)iA * TM_KS * TM_H, wv, lane);
+        load_tile_async(tiles[be[1]], a.hE + (size_t)iB * TM_KS * TM_H, wv, lane);
+        __syncthreads();
+        gather(0, iA, 0);
+        gather(1, iB, 0);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) accA[rb][cb] = gai[0][cb] + gcj[0][rb][cb];
+        mma_tile<8, 2>(tiles[be[0]], w11, accA, lane);
+    }
+
+    for (int p = 0; p < npairs; ++p) {
+        const int iA = tile_of(2 * p), iB = tile_of(2 * p + 1);
+        const bool vB = 2 * p + 1 < n;
+        const bool has_next = p + 1 < npairs;
+        const int iA2 = tile_of(2 * p + 2), iB2 = tile_of(2 * p + 3);
+        float *gA = a.hE + (size_t)iA * TM_KS * TM_H, *gB = a.hE + (size_t)iB * TM_KS * TM_H;
+
+        // J1: V1(A) | M1(B)
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) accB[rb][cb] = gai[1][cb] + gcj[1][rb][cb];
+        mma_tile_with<8, 2>(tiles[be[1]], w11, accB, lane, [&](int kk) { gelu_block(accA, tiles[bx[0]], kk); });
+        __syncthreads();
+
+        // J2: M2(A) | V1(B)       (+ next pair's neighbour lists -> registers)
+        int nidxA = -1, nidxB = -1;
+        if (has_next && tid < TM_TILE) {
+            nidxA = a.E_idx[(size_t)iA2 * TM_KS + tid];
+            nidxB = a.E_idx[(size_t)iB2 * TM_KS + tid];
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) accA[rb][cb] = b12[cb];
+        mma_tile_with<8, 2>(tiles[bx[0]], w12, accA, lane, [&](int kk) { gelu_block(accB, tiles[bx[1]], kk); });
+        __syncthreads();
+
+        // J3: V2(A) | M2(B)
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) accB[rb][cb] = b12[cb];
+        mma_tile_with<8, 2>(tiles[bx[1]], w12, accB, lane, [&](int kk) { gelu_block(accA, tiles[by[0]], kk); });
+        __syncthreads();
+
+        // J4: M3(A) | V2(B)       (+ publish the next pair's neighbour lists)
+        if (has_next && tid < TM_TILE) {
+            s_idx[0][par ^ 1][tid] = nidxA;
+            s_idx[1][par ^ 1][tid] = nidxB;
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) accA[rb][cb] = b13[cb];
+        mma_tile_with<8, 2>(tiles[by[0]], w13, accA, lane, [&](int kk) { gelu_block(accB, tiles[by[1]], kk); });
+        __syncthreads();
+
+        // J5: V3(A) | M3(B)       (+ DMA of A' into y_A, request A' node rows)
+        if (has_next) {
+            load_tile_async(tiles[by[0]], a.hE + (size_t)iA2 * TM_KS * TM_H, wv, lane);
+            gather(0, iA2, par ^ 1);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) accB[rb][cb] = b13[cb];
+        mma_tile_with<8, 2>(tiles[by[1]], w13, accB, lane,
+                            [&](int kk) { resid_block(accA, tiles[be[0]], tiles[bx[0]], 0, kk); });
+        __syncthreads();
+
+        // J6: S(A), V3(B)         (+ DMA of B' into y_B, request B' node rows)
+        if (has_next) {
+            load_tile_async(tiles[by[1]], a.hE + (size_t)iB2 * TM_KS * TM_H, wv, lane);
+            gather(1, iB2, par ^ 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) resid_block(accB, tiles[be[1]], tiles[bx[1]], 1, k);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) store_rows(tiles[bx[0]], 0, par, gA, true, k);
+        __syncthreads();
+
+        // J7: M1(A') | S(B)       rotate A: (e, x, y) <- (y, x, e)
+        { const int t = be[0]; be[0] = by[0]; by[0] = t; }
+        if (has_next) {
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) accA[rb][cb] = gai[0][cb] + gcj[0][rb][cb];
+            mma_tile_with<8, 2>(tiles[be[0]], w11, accA, lane,
+                                [&](int kk) { store_rows(tiles[bx[1]], 1, par, gB, vB, kk); });
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) store_rows(tiles[bx[1]], 1, par, gB, vB, k);
+        }
+        { const int t = be[1]; be[1] = by[1]; by[1] = t; }
+        par ^= 1;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // node_update:  h <- mask * LN2(h1 + FFN(h1)),  h1 = LN1(h + (W3 Ssum + cnt b3) / 30)
 //   (EncLayer :826-832 / DecLayer :870-879; PositionWiseFeedForward :883-893)          48 residues per tile
 // ------------------------------------------------------------------------------------------------
@@ -482,8 +908,10 @@ int launch_node_proj(const float *h, const float *Wa, int lda, const float *ba, 
 int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
                int64_t T, float *Ssum, float *cnt, hipStream_t st) {
-    MsgArgs a{W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, Ssum, cnt, (int)T};
-    const int grid = grid_for(T, 2);
+    static const int skew = [] { const char *e = getenv("TMPNN_MSG_SKEW"); return e ? atoi(e) : 0; }();
+    MsgArgs a{W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, Ssum, cnt, (int)T, skew};
+    static const int wg_per_cu = [] { const char *e = getenv("TMPNN_MSG_WG_PER_CU"); return e ? atoi(e) : 2; }();
+    const int grid = grid_for(T, wg_per_cu);
     if (dec) { tm_prof_begin("dec_msg", st); msg_kernel<true><<<grid, TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
     else { tm_prof_begin("enc_msg", st); msg_kernel<false><<<grid, TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
     return tm_check_launch(dec ? "dec_msg" : "enc_msg");
@@ -493,6 +921,24 @@ int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_i
     EdgeArgs a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
     const int grid = grid_for(T, 1);
     tm_prof_begin("enc_edge", st);
+    // The ping-pong variant is bit-identical to the classic kernel but measured 8-10 % slower on MI355X;
+    // it stays selectable for experiments: ablation code 16, or TMPNN_ENC_EDGE_PP=1 in the environment.
+    static const bool use_pp = [] { const char *e = getenv("TMPNN_ENC_EDGE_PP"); return e != nullptr && e[0] == '1'; }();
+    if (abl == 64) {
+        enc_edge2_kernel<<<grid_for(T, 2), TM_THREADS, 0, st>>>(a);
+        tm_prof_end(st);
+        return tm_check_launch("enc_edge2");
+    }
+    if (abl == 32) {
+        enc_edge8_kernel<<<grid, 512, 0, st>>>(a);
+        tm_prof_end(st);
+        return tm_check_launch("enc_edge8");
+    }
+    if ((abl == 0 && use_pp) || abl == 16) {
+        enc_edge_pp_kernel<<<grid, TM_THREADS, 0, st>>>(a);
+        tm_prof_end(st);
+        return tm_check_launch("enc_edge_pp");
+    }
     switch (abl) {
         case 0: enc_edge_kernel<0><<<grid, TM_THREADS, 0, st>>>(a); break;
         case 1: enc_edge_kernel<1><<<grid, TM_THREADS, 0, st>>>(a); break;
@@ -514,4 +960,39 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
     const int64_t tiles = (T + TM_TILE - 1) / TM_TILE;
     { tm_prof_begin("node_update", st); node_update_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
     return tm_check_launch("node_update");
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// clock probe (tools/clock_probe.py): every workgroup runs a dependent-free stream of fp32 MFMAs fed from LDS, like the
+// GEMM phases of the edge kernels, and reports shader cycles (s_memtime) against the 100 MHz constant clock.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TM_THREADS, 1) void clock_probe_kernel(int iters, unsigned long long *out, float *sink) {
+    __shared__ __attribute__((aligned(16))) float tile[TM_TILE * TM_H];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int k = tid; k < TM_TILE * TM_H; k += TM_THREADS) tile[k] = 1e-3f * (float)(k & 255);
+    float w[2][32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { w[0][k] = 1e-3f * (float)(k + lane); w[1][k] = 1e-3f * (float)(k - lane); }
+    f4 acc[3][2];
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const unsigned long long c0 = __builtin_readcyclecounter(), t0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) mma_tile<8, 2>(tile, w, acc, lane);
+    const unsigned long long c1 = __builtin_readcyclecounter(), t1 = wall_clock64();
+    float sum = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) sum += acc[rb][cb].x + acc[rb][cb].w;
+    if (sum == 123.456f) sink[tid] = sum;
+    if (tid == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = t1 - t0; }
+}
+
+int launch_clock_probe(int blocks, int iters, unsigned long long *out, float *sink, hipStream_t st) {
+    clock_probe_kernel<<<blocks, TM_THREADS, 0, st>>>(iters, out, sink);
+    return tm_check_launch("clock_probe");
 }
