@@ -146,6 +146,25 @@ int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const int32_t *S
                       float *log_probs_opt, int32_t *E_idx_opt, void *workspace, size_t workspace_bytes,
                       tmpnn_stream_t stream);
 
+/* ---- host side: native PDB reader + packer ------------------------------------------
+ * Replaces alt_parse_PDB (protein_mpnn_utils.py:183-350) + the packing of tied_featurize (:353-605) for one
+ * structure: one pass over the file, all requested chains. `chains` = string of one-letter chain ids in the
+ * order to concatenate them ("A", "AB", ...); NULL or "" = every chain present (A-Z, a-z, 0-9 order).
+ * HOST pointers here (the only entry points that are not device-side). */
+typedef struct tmpnn_pdb tmpnn_pdb_t;
+int tmpnn_pdb_parse(const char *path, const char *chains, tmpnn_pdb_t **out);
+/* n files on n_threads host threads; on failure every handle is released and outs[] is NULL. */
+int tmpnn_pdb_parse_batch(const char *const *paths, const char *const *chains, int n, int n_threads,
+                          tmpnn_pdb_t **outs);
+int64_t tmpnn_pdb_length(const tmpnn_pdb_t *p);      /* total residues L over the concatenated chains */
+int tmpnn_pdb_num_chains(const tmpnn_pdb_t *p);
+/* Any output may be NULL. X [L,4,3] fp32 with NaN -> 0, S [L] (ALPHABET index, gap -> 20), mask [L] (1 = all
+ * four backbone atoms present), residue_idx [L] = 100 (c-1) + position, chain_enc [L] = c (1-based),
+ * seq [L+1] = the parser's one-letter sequence ('-' at numbering gaps / unknown residues), NUL-terminated. */
+int tmpnn_pdb_fill(const tmpnn_pdb_t *p, float *X, int32_t *S, float *mask, int32_t *residue_idx,
+                   int32_t *chain_enc, char *seq);
+void tmpnn_pdb_free(tmpnn_pdb_t *p);
+
 /* ---- measurement hook ------------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events recorded on the launch stream around every kernel the
  * library launches (bench.py's roofline leg; not thread-safe; off by default). enable(1) starts a

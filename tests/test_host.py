@@ -122,3 +122,39 @@ def test_csv_writer_schema(tmp_path):
     assert lines[0] == ",Model,Dataset,ddG_pred,position,wildtype,mutation,pdb,chain"     # examples/ThermoMPNN_inference_2OCJ.csv:1
     assert lines[1] == "0,ThermoMPNN,2OCJ,-0.25,0,S,A,2OCJ,A"
     assert pdb_id_of("/x/y/2OCJ.pdb") == "2OCJ" and first_chain(PDB) == "A"
+
+
+@pytest.mark.parametrize("path,chains", [(PDB, "A"), (PDB, ["A", "B"]), (PDB, "BA"), (GAP, "A"), (PDB, None)])
+def test_native_parser_equals_python_path(path, chains):
+    """csrc/tmpnn_pdb.cpp == tied_featurize(alt_parse_PDB(...)) on the tensors the hot path consumes."""
+    from thermompnn_amd import native_pdb
+    d = pdb_io.alt_parse_PDB(path, chains)
+    X, S, mask, _, _, chain_enc, *rest = pdb_io.tied_featurize(d, "cpu", None)
+    n = native_pdb.parse_pdb(path, chains)
+    assert n["seq"] == d[0]["seq"] and n["num_of_chains"] == d[0]["num_of_chains"] and n["name"] == d[0]["name"]
+    np.testing.assert_array_equal(n["X"], X[0].numpy())
+    np.testing.assert_array_equal(n["S"], S[0].numpy())
+    np.testing.assert_array_equal(n["mask"], mask[0].numpy())
+    np.testing.assert_array_equal(n["residue_idx"], rest[6][0].numpy())
+    np.testing.assert_array_equal(n["chain_enc"], chain_enc[0].numpy())
+
+
+def test_native_parser_batch_and_errors(tmp_path):
+    from thermompnn_amd import native_pdb
+    from thermompnn_amd._lib import TmpnnError
+    many = native_pdb.parse_pdbs([PDB, GAP, PDB] * 4, ["A", "A", "AB"] * 4, n_threads=4)
+    assert [len(m["seq"]) for m in many] == [194, 194, 388] * 4
+    assert many[1]["seq"].count("-") == 3 and many[1]["mask"].sum() == 194 - 4
+    toy = tmp_path / "toy2.pdb"
+    toy.write_text("HETATM    5  N   MSE A   2       3.332   1.536   0.000  1.00  0.00           N\n"
+                   "ATOM      9  CA  GLY A   2A      7.000   3.000   0.000  1.00  0.00           C\n"
+                   "ATOM     11  CA  UNK A   5       8.000   4.000   0.000  1.00  0.00           C\n")
+    t = native_pdb.parse_pdb(str(toy), "A")
+    assert t["seq"] == "MG---" and t["S"].tolist() == [10, 5, 20, 20, 20] and t["mask"].sum() == 0
+    with pytest.raises(TmpnnError, match="cannot open"):
+        native_pdb.parse_pdb("/nonexistent.pdb", "A")
+    bad = tmp_path / "bad.pdb"
+    bad.write_text("ATOM      1  N   ALA A   1      xx.000   0.000   0.000\n")
+    with pytest.raises(TmpnnError, match="malformed"):
+        native_pdb.parse_pdbs([PDB, str(bad)], ["A", "A"])
+    assert native_pdb.parse_pdbs([]) == []

@@ -42,6 +42,12 @@ SIGNATURES = {
     "tmpnn_seq_embed": (_i, [_p, _p, _i64, _p, _p]),
     "tmpnn_log_probs": (_i, [_p, _p, _i64, _p, _p]),
     "tmpnn_ddg_head": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p]),
+    "tmpnn_pdb_parse": (_i, [C.c_char_p, C.c_char_p, C.POINTER(_p)]),
+    "tmpnn_pdb_parse_batch": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _i, _i, C.POINTER(_p)]),
+    "tmpnn_pdb_length": (_i64, [_p]),
+    "tmpnn_pdb_num_chains": (_i, [_p]),
+    "tmpnn_pdb_fill": (_i, [_p, _p, _p, _p, _p, _p, C.c_char_p]),
+    "tmpnn_pdb_free": (None, [_p]),
     "tmpnn_profile_enable": (_i, [_i]),
     "tmpnn_clock_probe": (_i, [_i, _i, _p, _p, _p]),
     "tmpnn_ablate_enc_edge": (_i, [_p, _i, _p, _p, _p, _i64, _i, _p]),

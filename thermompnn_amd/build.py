@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtmpnn.so")
-SOURCES = ["tmpnn_api.hip", "tmpnn_graph.hip", "tmpnn_layers.hip", "tmpnn_head.hip"]
+SOURCES = ["tmpnn_api.hip", "tmpnn_graph.hip", "tmpnn_layers.hip", "tmpnn_head.hip", "tmpnn_pdb.cpp"]
 HEADERS = ["tmpnn_common.h", "tmpnn_internal.h", os.path.join("..", "..", "include", "tmpnn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -36,7 +36,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
         objs.append(o)
         cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
