@@ -83,6 +83,11 @@ void tmpnn_weights_destroy(tmpnn_weights_t *w);
 int tmpnn_knn_topk(const float *X, const float *mask, const int32_t *offsets, int n_proteins,
                    int64_t T, int max_len, int K, int32_t *E_idx, float *D_nb, tmpnn_stream_t stream);
 
+/* compute_centrality (analysis/thermompnn_benchmarking.py:20-35): out[t] = #{other residues of the same protein
+ * with |CA_t - CA_j| < radius}; residues without coordinates (mask 0) get -1 and are never counted. int32 [T]. */
+int tmpnn_centrality(const float *X, const float *mask, const int32_t *offsets, int n_proteins, int64_t T,
+                     float radius, int32_t *out, tmpnn_stream_t stream);
+
 /* Replaces ProteinFeatures.forward after top-k (protein_mpnn_utils.py:1140-1180: 25 RBF blocks,
  * PositionalEncodings :896-908, edge_embedding, norm_edges) fused with W_e (:1229).
  * residue_idx, chain_enc: int32 [T]. h_E [T,48,128] <- W_e . LN(W_edge . [posenc | RBF]) + b.

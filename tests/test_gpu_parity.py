@@ -408,3 +408,50 @@ def test_enc_edge_kernel_variants_agree(engine):
     assert torch.equal(outs[0], outs[16]) and torch.equal(outs[0], outs[64])
     assert (outs[0] - outs[32]).abs().max() < 1e-5             # different LayerNorm-statistics merge order
     assert (outs[0][5, 40:] == 0).all()
+
+
+def test_centrality_and_baseline_and_scan(tmp_path, engine, synthetic_weights):
+    """compute_centrality, ProteinMPNNBaseline, the many-PDB SSM driver."""
+    from oracle import thermompnn_oracle as orc
+    from thermompnn_amd import native_pdb, pdb_io, ssm_scan, weights
+    from thermompnn_amd.ssm import mutation_objects
+    from thermompnn_amd.thermompnn_benchmarking import ProteinMPNNBaseline, compute_centrality
+    gap = os.path.join(GOLDEN, "2OCJ_gap_chainA.pdb")
+    pdb = pdb_io.alt_parse_PDB(gap, "A")
+    # centrality vs the reference formula (cdist, NaN -> 2r, count < r, minus 1)
+    ca = torch.tensor(pdb[0]["coords_chain_A"]["CA_chain_A"])
+    d = torch.nan_to_num(torch.cdist(ca, ca), nan=20.0)
+    want = (d < 10.0).sum(-1) - 1
+    got = compute_centrality(pdb[0]["coords_chain_A"], chain="A").cpu()
+    assert torch.equal(got, want) and int(got.min()) == -1
+    # ProteinMPNNBaseline: -log p(mut) from the HIP log_probs vs the oracle
+    class AD(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+    mp, _ = weights.split_transfer_state_dict(synthetic_weights)
+    os.makedirs(tmp_path / "vanilla_model_weights")
+    weights.save_vanilla_checkpoint(tmp_path / "vanilla_model_weights" / "v_48_020.pt", mp, 48)
+    cfg = AD(model=AD(load_pretrained=True, freeze_weights=True), platform=AD(thermompnn_dir=str(tmp_path)))
+    base = ProteinMPNNBaseline(cfg).eval().cuda()
+    muts = mutation_objects(pdb[0])[:60]
+    with torch.no_grad():
+        pred, lp = base(pdb, muts)
+    g = load_golden("2OCJ_A_gap")
+    assert lp.shape == (1, 194, 21)
+    np.testing.assert_allclose(lp[0].cpu().numpy(), g["log_probs"], atol=TOL_INTERMEDIATE, rtol=0)
+    assert abs(pred[3]["ddG"].item() + g["log_probs"][0, 3]) < 1e-5 and torch.equal(pred[3]["ddG"], -pred[3]["dTm"])
+    # many-PDB driver: native parse -> ragged batch -> CSV; values vs the reference golden
+    out = ssm_scan.main([os.path.join(GOLDEN, "2OCJ.pdb"), gap, "--chain", "A", "--synthetic_weights", "0", "--centrality",
+                         "--pick_best", "--out", str(tmp_path / "ssm.csv")])
+    import csv
+    rows = list(csv.DictReader(open(out)))
+    assert len(rows) == 194 + 191                              # one row per non-gap position
+    g0 = load_golden("2OCJ_A")
+    r = rows[17]
+    assert r["pdb"] == "2OCJ" and r["mutation"] == "A" and abs(float(r["ddG_pred"]) - g0["ddg"][17, 0]) <= TOL_DDG
+    best = "ACDEFGHIKLMNPQRSTVWY"[int(np.argmin(np.where(np.arange(20) == 1, np.inf, g0["ddg"][17])))]
+    assert r["best_AA"] == best
+    full = pdb_io.alt_parse_PDB(os.path.join(GOLDEN, "2OCJ.pdb"), "A")[0]
+    ca0 = torch.tensor(full["coords_chain_A"]["CA_chain_A"])
+    assert int(r["neighbors"]) == int(((torch.cdist(ca0, ca0) < 10.0).sum(-1) - 1)[17])
+    assert int(rows[194 + 17]["neighbors"]) == int(want[17])     # second file = the gapped structure

@@ -158,3 +158,21 @@ def test_native_parser_batch_and_errors(tmp_path):
     with pytest.raises(TmpnnError, match="malformed"):
         native_pdb.parse_pdbs([PDB, str(bad)], ["A", "A"])
     assert native_pdb.parse_pdbs([]) == []
+
+
+def test_retrieve_best_mutants_and_rows():
+    from thermompnn_amd.ssm_scan import COLUMNS, retrieve_best_mutants, rows_for_protein
+    t = np.zeros((3, 21), np.float32)
+    t[0, 1] = -2.0            # best at position 0 is C (index 1)
+    t[0, 4] = -1.0            # runner-up F
+    t[1, 7] = -0.5            # position 1: I
+    t[2, :] = 1.0
+    t[2, 3] = t[2, 9] = -3.0  # tie at position 2: first minimum wins (E before L), like idxmin
+    assert retrieve_best_mutants(t, allow_cys=True) == ["C", "I", "E"]
+    assert retrieve_best_mutants(t, allow_cys=False) == ["F", "I", "E"]
+    p = {"seq": "A-W", "name": "toy"}
+    rows = rows_for_protein(p, t, np.array([5, -1, 7]), "ThermoMPNN", "ds", pick_best=False, include_cys=False)
+    assert len(rows) == 2 * 19 and all(r["mutation"] != "C" for r in rows) and rows[0]["neighbors"] == 5
+    assert set(rows[0]) == set(COLUMNS)
+    best = rows_for_protein(p, t, None, "ThermoMPNN", "ds", pick_best=True, include_cys=True)
+    assert [(r["position"], r["mutation"], r["best_AA"]) for r in best] == [(0, "A", "C"), (2, "A", "E")]

@@ -31,6 +31,7 @@ SIGNATURES = {
     "tmpnn_weights_create": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _p, _sz, _p]),
     "tmpnn_weights_destroy": (None, [_p]),
     "tmpnn_knn_topk": (_i, [_p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
+    "tmpnn_centrality": (_i, [_p, _p, _p, _i, _i64, C.c_float, _p, _p]),
     "tmpnn_edge_featurize": (_i, [_p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),
     "tmpnn_gather_nodes": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "tmpnn_gather_rows_i32": (_i, [_p, _p, _i64, _i, _p, _p]),

@@ -318,6 +318,14 @@ extern "C" int tmpnn_knn_topk(const float *X, const float *mask, const int32_t *
     return launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, (hipStream_t)stream);
 }
 
+extern "C" int tmpnn_centrality(const float *X, const float *mask, const int32_t *offsets, int n_proteins, int64_t T,
+                                float radius, int32_t *out, tmpnn_stream_t stream) {
+    REQUIRE(n_proteins >= 0 && T >= 0 && T <= T_MAX && radius > 0.f, "centrality: bad argument");
+    if (T == 0 || n_proteins == 0) return TMPNN_OK;
+    REQUIRE(X && mask && offsets && out, "centrality: null pointer");
+    return launch_centrality(X, mask, offsets, n_proteins, T, radius, out, (hipStream_t)stream);
+}
+
 extern "C" int tmpnn_edge_featurize(const tmpnn_weights_t *w, const float *X, const int32_t *residue_idx,
                                     const int32_t *chain_enc, const int32_t *E_idx, const float *D_nb, int64_t T,
                                     float *h_E, float *E_opt, tmpnn_stream_t stream) {

@@ -311,9 +311,45 @@ __global__ __launch_bounds__(TM_THREADS) void gather_edges_kernel(const float *_
     }
 }
 
+// centrality: number of OTHER residues of the same protein whose CA lies within `radius` of this residue's CA
+// (compute_centrality, analysis/thermompnn_benchmarking.py:20-35: cdist, NaN -> 2*radius, count < radius, minus 1).
+// A residue without coordinates (mask 0) is at distance 2*radius from everything, itself included -> -1.
+__global__ __launch_bounds__(TM_THREADS) void centrality_kernel(const float *__restrict__ X, const float *__restrict__ mask,
+                                                                const int32_t *__restrict__ offsets, int N, int T,
+                                                                float radius, int32_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = blockIdx.x * 4 + wv; i < T; i += gridDim.x * 4) {
+        int lo = 0, hi = N;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (offsets[mid] <= i) lo = mid; else hi = mid;
+        }
+        const int s = offsets[lo], L = offsets[lo + 1] - s;
+        const float xi = X[(size_t)i * 12 + 3], yi = X[(size_t)i * 12 + 4], zi = X[(size_t)i * 12 + 5];
+        const bool vi = mask[i] > 0.f;
+        int cnt = 0;
+        for (int j = lane; j < L; j += 64) {
+            const float *c = X + (size_t)(s + j) * 12 + 3;
+            const float dx = c[0] - xi, dy = c[1] - yi, dz = c[2] - zi;
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            cnt += (vi && mask[s + j] > 0.f && d < radius) ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (lane == 0) out[i] = cnt - 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+int launch_centrality(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, float radius,
+                      int32_t *out, hipStream_t st) {
+    const int64_t blocks = (T + 3) / 4, cap = (int64_t)tm_num_cus() * 8;
+    { tm_prof_begin("centrality", st); centrality_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(X, mask, offsets, N, (int)T, radius, out); tm_prof_end(st); }
+    return tm_check_launch("centrality");
+}
+
 int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,
                int32_t *E_idx, float *D_nb, hipStream_t st) {
     const size_t lds = (size_t)4 * max_len * sizeof(float);

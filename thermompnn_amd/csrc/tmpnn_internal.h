@@ -46,6 +46,8 @@ void tm_prof_end(hipStream_t st);
 // tmpnn_graph.hip
 int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,
                int32_t *E_idx, float *D_nb, hipStream_t st);
+int launch_centrality(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, float radius,
+                      int32_t *out, hipStream_t st);
 int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx, const int32_t *cenc,
                      const int32_t *E_idx, const float *D_nb, int64_t T, float *h_E, float *E_opt, hipStream_t st);
 int launch_gather_rows(const float *nodes, const void *idx, int idx64, int64_t n_rows, int64_t rows_per_batch,

@@ -106,6 +106,13 @@ class Engine:
                                       _stream()), "tmpnn_knn_topk")
         return E_idx, D_nb
 
+    def centrality(self, X, mask, offsets, radius: float = 10.0):
+        X, mask, offsets = self._f32(X), self._f32(mask), self._i32(offsets)
+        out = torch.empty(X.shape[0], dtype=torch.int32, device=self.device)
+        check(self.lib.tmpnn_centrality(_ptr(X), _ptr(mask), _ptr(offsets), offsets.numel() - 1, X.shape[0], float(radius),
+                                        _ptr(out), _stream()), "tmpnn_centrality")
+        return out
+
     def edge_featurize(self, X, residue_idx, chain_enc, E_idx, D_nb, want_E: bool = False):
         X, ridx, cenc = self._f32(X), self._i32(residue_idx), self._i32(chain_enc)
         T = X.shape[0]

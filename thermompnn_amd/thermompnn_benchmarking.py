@@ -1,0 +1,71 @@
+"""Counterparts of the hot-path-adjacent symbols of /root/reference/analysis/thermompnn_benchmarking.py
+(SURVEY.md §8f ranks 2-3): compute_centrality (:20-35), ProteinMPNNBaseline (:38-65), get_trained_model (:78-84).
+Metrics / dataset drivers of that file stay out of scope."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .datasets import ALPHABET
+from .engine import _ptr, _stream, check
+from .pdb_io import tied_featurize
+from .protein_mpnn_utils import _EngineOwner
+from .transfer_model import TransferModel, get_protein_mpnn
+from .weights import load_thermompnn_checkpoint
+
+
+def compute_centrality(xyz, basis_atom: str = "CA", radius: float = 10.0, core_threshold: int = 20,
+                       surface_threshold: int = 15, backup_atom: str = "C", chain: str = "A",
+                       device="cuda") -> torch.Tensor:
+    """Number of neighbours within ``radius`` of each residue's basis atom, minus self (reference :20-35).
+    ``xyz`` = a parsed ``coords_chain_X`` dict. Runs the HIP kernel; returns an int tensor on ``device``."""
+    coords = np.asarray(xyz[basis_atom + f"_chain_{chain}"], dtype=np.float64)
+    L = coords.shape[0]
+    ok = np.isfinite(coords).all(1)
+    X = np.zeros((L, 4, 3), np.float32)
+    X[:, 1] = np.nan_to_num(coords)                       # the kernel reads the CA slot
+    dev = torch.device(device)
+    Xd = torch.from_numpy(X).to(dev)
+    md = torch.from_numpy(ok.astype(np.float32)).to(dev)
+    off = torch.tensor([0, L], dtype=torch.int32, device=dev)
+    out = torch.empty(L, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().tmpnn_centrality(_ptr(Xd), _ptr(md), _ptr(off), 1, L, float(radius), _ptr(out), _stream()),
+              "tmpnn_centrality")
+    return out.long()
+
+
+class ProteinMPNNBaseline(_EngineOwner):
+    """ProteinMPNN as a ddG proxy: ddG = -log p(mutant aa | structure) (reference :38-65)."""
+
+    def __init__(self, cfg, version="v_48_020.pt"):
+        super().__init__()
+        self.prot_mpnn = get_protein_mpnn(cfg, version=version)
+        self.k_neighbors = self.prot_mpnn.k_neighbors
+
+    def forward(self, pdb, mutations, tied_feat=True):
+        device = next(self.parameters()).device
+        feats = tied_featurize([pdb[0]], device, None, None, None, None, None, None, ca_only=False)
+        X, S, mask, chain_M, chain_enc, residue_idx = feats[0], feats[1], feats[2], feats[4], feats[5], feats[12]
+        *_, log_probs = self.prot_mpnn(X, S, mask, chain_M, residue_idx, chain_enc, None)
+        out = []
+        for mut in mutations:
+            if mut is None:
+                out.append(None)
+                continue
+            pred = log_probs[0, mut.position, ALPHABET.index(mut.mutation)]
+            out.append({"ddG": -torch.unsqueeze(pred, 0), "dTm": torch.unsqueeze(pred, 0)})
+        return out, log_probs
+
+
+def get_trained_model(model_name, config, checkpt_dir="models/", override_custom=False):
+    """Load a ThermoMPNN Lightning checkpoint into the HIP-backed TransferModel (reference :78-84) without
+    importing Lightning: the ``model.`` prefix of TransferModelPL is stripped by the loader."""
+    import os
+    path = model_name if override_custom else os.path.join(config.platform.thermompnn_dir, checkpt_dir, model_name)
+    model = TransferModel(config)
+    model.load_state_dict(load_thermompnn_checkpoint(path))
+    return model
