@@ -94,19 +94,19 @@ __device__ __forceinline__ void load_wfrag(const float *__restrict__ W, int ld, 
 }
 
 // acc[rb][cb] += W_cb . tile^T over K = 16*NK16, for the 3 row blocks of a 48-row tile.
-template <int NK16, int NCB, int RS = 128>
+template <int NK16, int NCB, int RS = 128, int NRB = 3>   // NRB = 16-row blocks in the tile (3 = 48 rows)
 __device__ __forceinline__ void mma_tile(const float *tile, const float (&w)[NCB][NK16 * 4],
-                                         f4 (&acc)[3][NCB], int lane) {
+                                         f4 (&acc)[NRB][NCB], int lane) {
     const int m = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < NK16; ++kk) {
-        f4 a[3];
+        f4 a[NRB];
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) a[rb] = ld4(tile + chunk_off<RS>(16 * rb + m, 4 * kk + q));
+        for (int rb = 0; rb < NRB; ++rb) a[rb] = ld4(tile + chunk_off<RS>(16 * rb + m, 4 * kk + q));
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb)
+            for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma16(w[cb][4 * kk + s], a[rb][s], acc[rb][cb]);
     }
@@ -156,9 +156,10 @@ __device__ __forceinline__ void mma_tile_with(const float *tile, const float (&w
 
 // Cooperative load of a contiguous [48,128] fp32 block from global into a swizzled LDS tile
 // (coalesced 16-byte loads; 6 per thread). rows_valid < 48 zero-fills the tail rows.
+template <int NRB = 3>
 __device__ __forceinline__ void load_tile(float *tile, const float *__restrict__ src, int rows_valid, int tid) {
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < 2 * NRB; ++it) {
         const int idx = it * TM_THREADS + tid;
         const int row = idx >> 5, c = idx & 31;
         f4 v = row < rows_valid ? ld4(src + (size_t)idx * 4) : f4{0.f, 0.f, 0.f, 0.f};

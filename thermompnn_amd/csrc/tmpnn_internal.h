@@ -33,7 +33,8 @@ struct tmpnn_weights {
 
 // scratch carved out of the caller's workspace for the message-passing layers
 struct LayerWs {
-    float *P;      // [T,256] node projections (A | C)
+    float *P;      // [T,256] node projections (A | C) for the message pass
+    float *P2;     // [T,256] node projections for the encoder edge update
     float *Ssum;   // [T,128] sum_k mask_k * m2_k
     float *cnt;    // [T]     sum_k mask_k
 };
@@ -60,10 +61,11 @@ int launch_node_proj(const float *h, const float *Wa, int lda, const float *ba, 
 int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
                int64_t T, float *Ssum, float *cnt, hipStream_t st);
+struct NodeProj { const float *Wa; int lda; const float *ba; const float *Wc; int ldc; float *P; };   // P [T,256]
 int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
                        const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,
-                       float *h_out, hipStream_t st);
+                       float *h_out, const NodeProj *p0, const NodeProj *p1, hipStream_t st);
 int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st, int abl = 0);
 
 // tmpnn_head.hip

@@ -785,38 +785,47 @@ __global__ __launch_bounds__(TM_THREADS, 1) void enc_edge_pp_kernel(EdgeArgs a) 
 
 // ------------------------------------------------------------------------------------------------
 // node_update:  h <- mask * LN2(h1 + FFN(h1)),  h1 = LN1(h + (W3 Ssum + cnt b3) / 30)
-//   (EncLayer :826-832 / DecLayer :870-879; PositionWiseFeedForward :883-893)          48 residues per tile
+//   (EncLayer :826-832 / DecLayer :870-879; PositionWiseFeedForward :883-893)
+// followed, in the same kernel, by up to two node projections of the NEW state (what node_proj computes):
+//   P_k[t, 0:128] = Wa_k h_t + ba_k ; P_k[t, 128:256] = Wc_k h_t
+// (k = 0: the edge update of this encoder layer, k = 1: the message pass of the NEXT layer), which removes two
+// launches and two re-reads of h per layer. Tile = 16*NRB residues: 48 for batches, 16 when T is small so that a
+// single protein still spreads over more CUs (the weights stream from L2 either way).
 // ------------------------------------------------------------------------------------------------
+struct ProjSpec { const float *Wa; int lda; const float *ba; const float *Wc; int ldc; float *P; };
 struct NodeArgs {
     const float *W3, *b3, *n1w, *n1b, *Win, *bin, *Wout, *bout, *n2w, *n2b;
     const float *h_in, *Ssum, *cnt, *mask;
     float *h_out;
     int T;
+    ProjSpec proj[2];       // proj[k].P == nullptr -> not requested
 };
 
+template <int NRB>
 __global__ __launch_bounds__(TM_THREADS, 2) void node_update_kernel(NodeArgs a) {
-    __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];
+    constexpr int ROWS = 16 * NRB;
+    __shared__ __attribute__((aligned(16))) float tA[ROWS * TM_H];
+    __shared__ __attribute__((aligned(16))) float tB[ROWS * TM_H];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31;
-    const int n_tiles = (a.T + TM_TILE - 1) / TM_TILE;
+    const int n_tiles = (a.T + ROWS - 1) / ROWS;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int r0 = tile * TM_TILE;
-        load_tile(tA, a.Ssum + (size_t)r0 * TM_H, min(TM_TILE, a.T - r0), tid);
+        const int r0 = tile * ROWS;
+        load_tile<NRB>(tA, a.Ssum + (size_t)r0 * TM_H, min(ROWS, a.T - r0), tid);
         __syncthreads();
 
         float wf[2][32];
-        f4 acc[3][2];
+        f4 acc[NRB][2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) load_wfrag<8>(a.W3, TM_H, 32 * wv + 16 * cb, 0, TM_H, wf[cb], lane);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f4{0.f, 0.f, 0.f, 0.f};
-        mma_tile<8, 2>(tA, wf, acc, lane);
+        mma_tile<8, 2, 128, NRB>(tA, wf, acc, lane);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
+        for (int rb = 0; rb < NRB; ++rb) {
             const int row = r0 + 16 * rb + m;
             const bool ok = row < a.T;
             const float c = ok ? a.cnt[row] : 0.f;
@@ -832,20 +841,20 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_update_kernel(NodeArgs a) 
         {   // LN1 in place
             const f4 g4 = ld4(a.n1w + 4 * c32), b4 = ld4(a.n1b + 4 * c32);
 #pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int row = 12 * wv + 2 * it + (lane >> 5);
+            for (int it = 0; it < 2 * NRB; ++it) {
+                const int row = 4 * NRB * wv + 2 * it + (lane >> 5);
                 float *p = tB + chunk_off(row, c32);
                 st4(p, layer_norm_row(ld4(p), g4, b4));
             }
         }
         __syncthreads();
 
-        f4 out[3][2];
+        f4 out[NRB][2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const f4 b = ld4(a.bout + 32 * wv + 16 * cb + 4 * q);
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) out[rb][cb] = b;
+            for (int rb = 0; rb < NRB; ++rb) out[rb][cb] = b;
         }
         for (int c = 0; c < 4; ++c) {           // FFN hidden 512 in four 128-wide chunks
 #pragma unroll
@@ -854,36 +863,66 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_update_kernel(NodeArgs a) 
                 load_wfrag<8>(a.Win, TM_H, n0, 0, 512, wf[cb], lane);
                 const f4 b = ld4(a.bin + n0 + 4 * q);
 #pragma unroll
-                for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = b;
+                for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = b;
             }
-            mma_tile<8, 2>(tB, wf, acc, lane);
+            mma_tile<8, 2, 128, NRB>(tB, wf, acc, lane);
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb)
+            for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
                     st4(tA + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(acc[rb][cb]));
             __syncthreads();
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) load_wfrag<8>(a.Wout, 512, 32 * wv + 16 * cb, 128 * c, TM_H, wf[cb], lane);
-            mma_tile<8, 2>(tA, wf, out, lane);
+            mma_tile<8, 2, 128, NRB>(tA, wf, out, lane);
             __syncthreads();
         }
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 const int off = chunk_off(16 * rb + m, 8 * wv + 4 * cb + q);
                 st4(tA + off, ld4(tB + off) + out[rb][cb]);
             }
         __syncthreads();
-        {   // LN2, mask, coalesced store
+        {   // LN2, mask, coalesced store; the new state also stays in tB for the projections
             const f4 g4 = ld4(a.n2w + 4 * c32), b4 = ld4(a.n2b + 4 * c32);
 #pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int row = 12 * wv + 2 * it + (lane >> 5);
+            for (int it = 0; it < 2 * NRB; ++it) {
+                const int row = 4 * NRB * wv + 2 * it + (lane >> 5);
                 const int grow = r0 + row;
-                const f4 y = layer_norm_row(ld4(tA + chunk_off(row, c32)), g4, b4);
-                if (grow < a.T) st4(a.h_out + (size_t)grow * TM_H + 4 * c32, y * a.mask[grow]);
+                f4 y = layer_norm_row(ld4(tA + chunk_off(row, c32)), g4, b4);
+                y = grow < a.T ? y * a.mask[grow] : f4{0.f, 0.f, 0.f, 0.f};
+                st4(tB + chunk_off(row, c32), y);
+                if (grow < a.T) st4(a.h_out + (size_t)grow * TM_H + 4 * c32, y);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const ProjSpec &ps = a.proj[k];
+            if (ps.P == nullptr) continue;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int n0 = 32 * wv + 16 * cb;
+                    if (half) load_wfrag<8>(ps.Wc, ps.ldc, n0, 0, TM_H, wf[cb], lane);
+                    else load_wfrag<8>(ps.Wa, ps.lda, n0, 0, TM_H, wf[cb], lane);
+                    const f4 b = half ? f4{0.f, 0.f, 0.f, 0.f} : ld4(ps.ba + n0 + 4 * q);
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = b;
+                }
+                mma_tile<8, 2, 128, NRB>(tB, wf, acc, lane);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const int row = r0 + 16 * rb + m;
+                    if (row < a.T) {
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+                            st4(ps.P + (size_t)row * 256 + 128 * half + 32 * wv + 16 * cb + 4 * q, acc[rb][cb]);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -955,13 +994,23 @@ int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_i
 int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
                        const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,
-                       float *h_out, hipStream_t st) {
-    NodeArgs a{W3, b3, n1w, n1b, Win, bin, Wout, bout, n2w, n2b, h_in, Ssum, cnt, mask, h_out, (int)T};
-    const int64_t tiles = (T + TM_TILE - 1) / TM_TILE;
-    { tm_prof_begin("node_update", st); node_update_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
+                       float *h_out, const NodeProj *p0, const NodeProj *p1, hipStream_t st) {
+    NodeArgs a{W3, b3, n1w, n1b, Win, bin, Wout, bout, n2w, n2b, h_in, Ssum, cnt, mask, h_out, (int)T, {}};
+    const NodeProj *ps[2] = {p0, p1};
+    for (int k = 0; k < 2; ++k)
+        a.proj[k] = ps[k] ? ProjSpec{ps[k]->Wa, ps[k]->lda, ps[k]->ba, ps[k]->Wc, ps[k]->ldc, ps[k]->P}
+                          : ProjSpec{nullptr, 0, nullptr, nullptr, 0, nullptr};
+    tm_prof_begin("node_update", st);
+    if (T < (int64_t)48 * tm_num_cus()) {       // small batch: 16-residue tiles spread one protein over 3x more CUs
+        const int64_t tiles = (T + 15) / 16;
+        node_update_kernel<1><<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a);
+    } else {
+        const int64_t tiles = (T + TM_TILE - 1) / TM_TILE;
+        node_update_kernel<3><<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a);
+    }
+    tm_prof_end(st);
     return tm_check_launch("node_update");
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // clock probe (tools/clock_probe.py): every workgroup runs a dependent-free stream of fp32 MFMAs fed from LDS, like the
