@@ -160,20 +160,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # TMPNN_BENCH_ONE_DEVICE=1 + TMPNN_BENCH_BACKEND=gloo: smoke-test the N>1 code path on a 1-GPU box (all ranks on
+    # cuda:0, collectives staged through gloo). The real multi-GPU run uses one GPU per rank over RCCL.
+    one_device = os.environ.get("TMPNN_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("TMPNN_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     lib = _lib.load()
     eng = Engine(synthetic_state_dict(0), device, 48)
     B, L = args.proteins_per_gpu, args.length
     batch = build_batch(B, L, 100000 * rank, device)
     out = {"ddg": torch.empty((batch["T"], 21), dtype=torch.float32, device=device)}
-    gathered = torch.empty((world, batch["T"], 21), dtype=torch.float32, device=device) if world > 1 else None
+    gathered = torch.empty((world * batch["T"], 21), dtype=torch.float32, device=device) if world > 1 else None
 
     def step():
         eng.ssm_forward(batch["X"], batch["S"], batch["mask"], batch["ridx"], batch["cenc"], batch["offsets"],
