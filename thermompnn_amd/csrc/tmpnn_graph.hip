@@ -3,6 +3,8 @@
 // Reference semantics: ProteinFeatures (/root/reference/protein_mpnn_utils.py:1084-1180),
 // PositionalEncodings (:896-908), gather_edges (:763-767), gather_nodes (:770-778).
 // Nothing here materialises an L x L matrix: distances are computed per row (kNN) or per edge (RBF).
+#include <stdlib.h>
+
 #include "tmpnn_common.h"
 #include "tmpnn_internal.h"
 
@@ -130,7 +132,13 @@ __device__ __forceinline__ void atoms5(const float *__restrict__ x, float *out /
     }
 }
 
-__global__ __launch_bounds__(TM_THREADS, 1) void featurize_kernel(FeatArgs a) {
+// NW wavefronts per workgroup (1 workgroup per CU): NW = 8 puts two wavefronts on every SIMD, each owning ONE
+// 16-column block (132 weight VGPRs). The matrix-pipe work per SIMD is unchanged, but the serial phases in front of
+// the GEMM (atom gather -> 1200 distances -> 19200 Gaussians) and the LayerNorm / store phases run on twice the
+// threads with twice the latency hiding — they were 50 % of this kernel's time with 4 wavefronts.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 1)) void featurize_kernel(FeatArgs a) {
+    constexpr int NT = 64 * NW, NCB = 8 / NW, RPW = TM_TILE / NW;    // threads, column blocks / wave, rows / wave
     __shared__ __attribute__((aligned(16))) float rbf[TM_TILE * RBF_RS];
     __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
     __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];
@@ -141,12 +149,13 @@ __global__ __launch_bounds__(TM_THREADS, 1) void featurize_kernel(FeatArgs a) {
     __shared__ int s_dpos[TM_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31;
+    const int col0 = (TM_H / NW) * wv, chunk0 = (32 / NW) * wv;
 
-    float wedge[2][100], we[2][32];
-    f4 be[2];
+    float wedge[NCB][100], we[NCB][32];
+    f4 be[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int n0 = 32 * wv + 16 * cb;
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int n0 = col0 + 16 * cb;
         load_wfrag<25>(a.edge_w, 416, n0, 16, TM_H, wedge[cb], lane);
         load_wfrag<8>(a.We_w, TM_H, n0, 0, TM_H, we[cb], lane);
         be[cb] = ld4(a.We_b + n0 + 4 * q);
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void featurize_kernel(FeatArgs a) {
             for (int k = 0; k < 15; ++k) s_self[k] = at[k];
         }
         __syncthreads();
-        for (int e = tid; e < TM_TILE * 25; e += TM_THREADS) {
+        for (int e = tid; e < TM_TILE * 25; e += NT) {
             const int mm = e / 25, p = e - mm * 25;
             float D;
             if (p == 0) {
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void featurize_kernel(FeatArgs a) {
             s_dist[mm][p] = D;
         }
         __syncthreads();
-        for (int e = tid; e < TM_TILE * 100; e += TM_THREADS) {   // 16 Gaussians per pair, 4 per thread (:1111-1119)
+        for (int e = tid; e < TM_TILE * 100; e += NT) {          // 16 Gaussians per pair, 4 per thread (:1111-1119)
             const int mm = e / 100, c = e - mm * 100;
             const float D = s_dist[mm][c >> 2];
             const int r0 = (c & 3) * 4;
@@ -202,22 +211,22 @@ __global__ __launch_bounds__(TM_THREADS, 1) void featurize_kernel(FeatArgs a) {
         }
         __syncthreads();
 
-        f4 acc[3][2];
+        f4 acc[3][NCB];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
-            const float *pt = a.pos_table + s_dpos[16 * rb + m] * TM_H + 32 * wv + 4 * q;
+            const float *pt = a.pos_table + s_dpos[16 * rb + m] * TM_H + col0 + 4 * q;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = ld4(pt + 16 * cb);
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = ld4(pt + 16 * cb);
         }
-        mma_tile<25, 2, RBF_RS>(rbf, wedge, acc, lane);
+        mma_tile<25, NCB, RBF_RS>(rbf, wedge, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) st4(tA + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), acc[rb][cb]);
+            for (int cb = 0; cb < NCB; ++cb) st4(tA + chunk_off(16 * rb + m, chunk0 + 4 * cb + q), acc[rb][cb]);
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {                         // norm_edges (:1179)
-            const int row = 12 * wv + 2 * it + (lane >> 5);
+        for (int it = 0; it < RPW / 2; ++it) {                   // norm_edges (:1179)
+            const int row = RPW * wv + 2 * it + (lane >> 5);
             float *p = tA + chunk_off(row, c32);
             const f4 y = layer_norm_row(ld4(p), g4, b4);
             st4(p, y);
@@ -230,16 +239,16 @@ __global__ __launch_bounds__(TM_THREADS, 1) void featurize_kernel(FeatArgs a) {
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = be[cb];
-        mma_tile<8, 2>(tA, we, acc, lane);                        // W_e (:1229)
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = be[cb];
+        mma_tile<8, NCB>(tA, we, acc, lane);                      // W_e (:1229)
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) st4(tB + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), acc[rb][cb]);
+            for (int cb = 0; cb < NCB; ++cb) st4(tB + chunk_off(16 * rb + m, chunk0 + 4 * cb + q), acc[rb][cb]);
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int row = 12 * wv + 2 * it + (lane >> 5);
+        for (int it = 0; it < RPW / 2; ++it) {
+            const int row = RPW * wv + 2 * it + (lane >> 5);
             const f4 y = s_idx[row] >= 0 ? ld4(tB + chunk_off(row, c32)) : f4{0.f, 0.f, 0.f, 0.f};
             st4(a.hE + ((size_t)i * TM_KS + row) * TM_H + 4 * c32, y);
         }
@@ -374,7 +383,11 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
     for (int i = 0; i < 16; ++i)   // torch.linspace(2, 22, 16): double arithmetic, symmetric halves, cast to fp32
         a.mu[i] = i < 8 ? (float)(2.0 + (20.0 / 15.0) * i) : (float)(22.0 - (20.0 / 15.0) * (15 - i));
     const int64_t cap = tm_num_cus();
-    { tm_prof_begin("featurize", st); featurize_kernel<<<(int)(T < cap ? T : cap), TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
+    static const int nw = [] { const char *e = getenv("TMPNN_FEAT_WAVES"); return e ? atoi(e) : 8; }();
+    tm_prof_begin("featurize", st);
+    if (nw == 4) featurize_kernel<4><<<(int)(T < cap ? T : cap), 256, 0, st>>>(a);
+    else featurize_kernel<8><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
+    tm_prof_end(st);
     return tm_check_launch("edge_featurize");
 }
 

@@ -66,7 +66,7 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
                        const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,
                        float *h_out, const NodeProj *p0, const NodeProj *p1, hipStream_t st);
-int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st, int abl = 0);
+int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st, int abl = -1);   // -1 = shipped variant
 
 // tmpnn_head.hip
 int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg,

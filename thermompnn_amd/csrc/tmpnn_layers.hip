@@ -81,31 +81,29 @@ struct MsgArgs {
     int skew;                // start delay of the second half of the grid, in units of 64 cycles
 };
 
-template <bool DEC>
-__global__ __launch_bounds__(TM_THREADS, 2) void msg_kernel(MsgArgs a) {
+// NW wavefronts per workgroup, two workgroups per CU either way: NW = 4 -> 32 columns per wavefront (128 weight VGPRs,
+// 2 wavefronts per SIMD); NW = 8 -> 16 columns (64 weight VGPRs, <= 128 VGPRs in total, 4 wavefronts per SIMD).
+template <bool DEC, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void msg_kernel(MsgArgs a) {
+    constexpr int NT = 64 * NW, NCB = 8 / NW;
     __shared__ __attribute__((aligned(16))) float tE[TM_TILE * TM_H];
     __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
-    __shared__ float s_part[TM_H];
+    __shared__ float s_part[3][TM_H];
     __shared__ int s_idx[TM_TILE];
     __shared__ float s_ma[TM_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int col0 = (TM_H / NW) * wv, chunk0 = (32 / NW) * wv;
 
-    float w1[2][32], w2[2][32];
-    f4 bias2[2];
+    float w1[NCB][32], w2[NCB][32];
+    f4 bias2[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int n0 = 32 * wv + 16 * cb;
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int n0 = col0 + 16 * cb;
         load_wfrag<8>(a.W1e, a.ld1, n0, 0, TM_H, w1[cb], lane);
         load_wfrag<8>(a.W2, TM_H, n0, 0, TM_H, w2[cb], lane);
         bias2[cb] = ld4(a.b2 + n0 + 4 * q);
     }
 
-    // Two workgroups share every CU. A wavefront cannot overlap its own MFMAs with its own VALU work (measured,
-    // tools/probe/overlap_probe.hip: the costs add), but two wavefronts on one SIMD do overlap — provided they are in
-    // DIFFERENT phases. Identical workgroups started together stay phase-locked, so the second half of the grid
-    // starts a fraction of a tile period late (a.skew x 64 cycles).
-    if (a.skew > 0 && blockIdx.x >= (gridDim.x >> 1))
-        for (int k = 0; k < a.skew; k += 100) __builtin_amdgcn_s_sleep(100);
     const TileRange tr = xcd_tile_range(a.T);
     for (int i = tr.begin; i < tr.end; i += tr.step) {
         const float mi = a.mask[i];
@@ -114,10 +112,10 @@ __global__ __launch_bounds__(TM_THREADS, 2) void msg_kernel(MsgArgs a) {
             s_idx[tid] = j;
             s_ma[tid] = j < 0 ? 0.f : (DEC ? 1.f : mi * a.mask[j]);
         }
-        load_tile(tE, a.hE + (size_t)i * TM_KS * TM_H, TM_TILE, tid);
+        load_tile_async<NW>(tE, a.hE + (size_t)i * TM_KS * TM_H, wv, lane);
         __syncthreads();
 
-        f4 acc[3][2];
+        f4 acc[3][NCB];
         int jrow[3];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
@@ -125,8 +123,8 @@ __global__ __launch_bounds__(TM_THREADS, 2) void msg_kernel(MsgArgs a) {
             jrow[rb] = j < 0 ? i : j;
         }
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int n = 32 * wv + 16 * cb + 4 * q;
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int n = col0 + 16 * cb + 4 * q;
             if (DEC) {
 #pragma unroll
                 for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = f4{0.f, 0.f, 0.f, 0.f};
@@ -136,10 +134,10 @@ __global__ __launch_bounds__(TM_THREADS, 2) void msg_kernel(MsgArgs a) {
                 for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = ai + ld4(a.P + (size_t)jrow[rb] * 256 + 128 + n);
             }
         }
-        mma_tile<8, 2>(tE, w1, acc, lane);
+        mma_tile<8, NCB>(tE, w1, acc, lane);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int n = 32 * wv + 16 * cb + 4 * q;
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int n = col0 + 16 * cb + 4 * q;
             f4 ai;
             if (DEC) ai = ld4(a.P + (size_t)i * 256 + n);
 #pragma unroll
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(TM_THREADS, 2) void msg_kernel(MsgArgs a) {
                     const int j = jrow[rb];
                     v = ai + mi * (v + ld4(a.seq_table + a.S[j] * TM_H + n) + ld4(a.P + (size_t)j * 256 + 128 + n));
                 }
-                st4(tA + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(v));
+                st4(tA + chunk_off(16 * rb + m, chunk0 + 4 * cb + q), gelu4(v));
             }
         }
         __syncthreads();
@@ -157,29 +155,34 @@ __global__ __launch_bounds__(TM_THREADS, 2) void msg_kernel(MsgArgs a) {
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = bias2[cb];
-        mma_tile<8, 2>(tA, w2, acc, lane);
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = bias2[cb];
+        mma_tile<8, NCB>(tA, w2, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             const float ma = s_ma[16 * rb + m];
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < NCB; ++cb) {
                 f4 v = gelu4(acc[rb][cb]) * ma;
                 if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
-                st4(tE + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), v);
+                st4(tE + chunk_off(16 * rb + m, chunk0 + 4 * cb + q), v);
             }
         }
         __syncthreads();
 
-        // per-node aggregation over the 48 slots: column sums, two 24-row halves
+        // per-node aggregation over the 48 slots: column sums over NT/128 row groups, combined in a fixed order
         {
-            const int n = tid & 127, half = tid >> 7;
+            constexpr int G = NT / TM_H, RPG = TM_TILE / G;       // groups, rows per group
+            const int n = tid & 127, grp = tid >> 7;
             float s = 0.f;
 #pragma unroll 8
-            for (int r = 24 * half; r < 24 * half + 24; ++r) s += tE[chunk_off(r, n >> 2) + (n & 3)];
-            if (half) s_part[n] = s;
+            for (int r = RPG * grp; r < RPG * grp + RPG; ++r) s += tE[chunk_off(r, n >> 2) + (n & 3)];
+            if (grp) s_part[grp - 1][n] = s;
             __syncthreads();
-            if (!half) a.Ssum[(size_t)i * TM_H + n] = s + s_part[n];
+            if (!grp) {
+#pragma unroll
+                for (int g = 0; g < G - 1; ++g) s += s_part[g][n];
+                a.Ssum[(size_t)i * TM_H + n] = s;
+            }
             if (tid == 128) {
                 float c = 0.f;
                 for (int r = 0; r < TM_TILE; ++r) c += s_ma[r];
@@ -947,12 +950,18 @@ int launch_node_proj(const float *h, const float *Wa, int lda, const float *ba, 
 int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
                int64_t T, float *Ssum, float *cnt, hipStream_t st) {
-    static const int skew = [] { const char *e = getenv("TMPNN_MSG_SKEW"); return e ? atoi(e) : 0; }();
-    MsgArgs a{W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, Ssum, cnt, (int)T, skew};
-    static const int wg_per_cu = [] { const char *e = getenv("TMPNN_MSG_WG_PER_CU"); return e ? atoi(e) : 2; }();
-    const int grid = grid_for(T, wg_per_cu);
-    if (dec) { tm_prof_begin("dec_msg", st); msg_kernel<true><<<grid, TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
-    else { tm_prof_begin("enc_msg", st); msg_kernel<false><<<grid, TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
+    MsgArgs a{W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, Ssum, cnt, (int)T, 0};
+    static const int nw = [] { const char *e = getenv("TMPNN_MSG_WAVES"); return e ? atoi(e) : 4; }();
+    const int grid = grid_for(T, 2);
+    tm_prof_begin(dec ? "dec_msg" : "enc_msg", st);
+    if (nw == 8) {
+        if (dec) msg_kernel<true, 8><<<grid, 512, 0, st>>>(a);
+        else msg_kernel<false, 8><<<grid, 512, 0, st>>>(a);
+    } else {
+        if (dec) msg_kernel<true, 4><<<grid, 256, 0, st>>>(a);
+        else msg_kernel<false, 4><<<grid, 256, 0, st>>>(a);
+    }
+    tm_prof_end(st);
     return tm_check_launch(dec ? "dec_msg" : "enc_msg");
 }
 
@@ -960,9 +969,11 @@ int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_i
     EdgeArgs a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
     const int grid = grid_for(T, 1);
     tm_prof_begin("enc_edge", st);
-    // The ping-pong variant is bit-identical to the classic kernel but measured 8-10 % slower on MI355X;
-    // it stays selectable for experiments: ablation code 16, or TMPNN_ENC_EDGE_PP=1 in the environment.
-    static const bool use_pp = [] { const char *e = getenv("TMPNN_ENC_EDGE_PP"); return e != nullptr && e[0] == '1'; }();
+    // Shipped form = the 8-wavefront kernel (code 32; 6 % faster than the 4-wavefront one on MI355X). The others stay
+    // selectable for experiments: TMPNN_ENC_EDGE_VARIANT = 1 (4-wavefront), 16 (ping-pong), 64 (2 workgroups per CU),
+    // or the ablation codes of tmpnn_ablate_enc_edge (0 there means the 4-wavefront kernel).
+    static const int variant = [] { const char *e = getenv("TMPNN_ENC_EDGE_VARIANT"); return e ? atoi(e) : 32; }();
+    if (abl < 0) abl = variant == 1 ? 0 : variant;
     if (abl == 64) {
         enc_edge2_kernel<<<grid_for(T, 2), TM_THREADS, 0, st>>>(a);
         tm_prof_end(st);
@@ -973,7 +984,7 @@ int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_i
         tm_prof_end(st);
         return tm_check_launch("enc_edge8");
     }
-    if ((abl == 0 && use_pp) || abl == 16) {
+    if (abl == 16) {
         enc_edge_pp_kernel<<<grid, TM_THREADS, 0, st>>>(a);
         tm_prof_end(st);
         return tm_check_launch("enc_edge_pp");
