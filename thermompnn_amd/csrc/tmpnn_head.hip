@@ -21,21 +21,23 @@ struct HeadArgs {
 
 __device__ __forceinline__ f4 relu4(f4 v) { return f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
 
+template <int NRB>   // tile = 16*NRB residues (chosen by the launcher for load balance / small batches)
 __global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
-    __shared__ __attribute__((aligned(16))) float tX[3][TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) float tY[3][TM_TILE * TM_H];
-    __shared__ int s_S[TM_TILE];
+    constexpr int ROWS = 16 * NRB;
+    __shared__ __attribute__((aligned(16))) float tX[3][ROWS * TM_H];
+    __shared__ __attribute__((aligned(16))) float tY[3][ROWS * TM_H];
+    __shared__ int s_S[ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-    const int n_tiles = (a.T + TM_TILE - 1) / TM_TILE;
+    const int n_tiles = (a.T + ROWS - 1) / ROWS;
     const float dw = a.ddg_w[0], db = a.ddg_b[0];
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int r0 = tile * TM_TILE, rows = min(TM_TILE, a.T - r0);
-        if (tid < TM_TILE) s_S[tid] = tid < rows ? a.S[r0 + tid] : 0;
-        load_tile(tX[0], a.hA + (size_t)r0 * TM_H, rows, tid);
-        load_tile(tX[1], a.hB + (size_t)r0 * TM_H, rows, tid);
+        const int r0 = tile * ROWS, rows = min(ROWS, a.T - r0);
+        if (tid < ROWS) s_S[tid] = tid < rows ? a.S[r0 + tid] : 0;
+        load_tile<NRB>(tX[0], a.hA + (size_t)r0 * TM_H, rows, tid);
+        load_tile<NRB>(tX[1], a.hB + (size_t)r0 * TM_H, rows, tid);
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {        // x[256:384] = W_s[S]
+        for (int it = 0; it < 2 * NRB; ++it) {  // x[256:384] = W_s[S]
             const int idx = it * TM_THREADS + tid, row = idx >> 5, c = idx & 31;
             const int s = row < rows ? a.S[r0 + row] : 0;
             st4(tX[2] + chunk_off(row, c), ld4(a.Ws + s * TM_H + 4 * c));
@@ -44,22 +46,22 @@ __global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
 
         // y = relu(Wc x + bc), 384 -> 384 in three 128-column groups
         for (int g = 0; g < 3; ++g) {
-            f4 acc[3][2];
+            f4 acc[NRB][2];
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 const f4 b = ld4(a.conv_b + 128 * g + 32 * wv + 16 * cb + 4 * q);
 #pragma unroll
-                for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = b;
+                for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = b;
             }
             for (int kt = 0; kt < 3; ++kt) {
                 float wf[2][32];
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
                     load_wfrag<8>(a.conv_center, 384, 128 * g + 32 * wv + 16 * cb, 128 * kt, 384, wf[cb], lane);
-                mma_tile<8, 2>(tX[kt], wf, acc, lane);
+                mma_tile<8, 2, 128, NRB>(tX[kt], wf, acc, lane);
             }
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb)
+            for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
                     st4(tY[g] + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), relu4(acc[rb][cb]));
@@ -67,33 +69,33 @@ __global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
         __syncthreads();
 
         {   // 384 -> 64, relu; wavefront w owns columns 16w..16w+15 -> tX[0][:, 0:64]
-            f4 acc[3][1];
+            f4 acc[NRB][1];
             const f4 b = ld4(a.b1 + 16 * wv + 4 * q);
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b;
+            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
             for (int kt = 0; kt < 3; ++kt) {
                 float wf[1][32];
                 load_wfrag<8>(a.w1, 384, 16 * wv, 128 * kt, 64, wf[0], lane);
-                mma_tile<8, 1>(tY[kt], wf, acc, lane);
+                mma_tile<8, 1, 128, NRB>(tY[kt], wf, acc, lane);
             }
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) st4(tX[0] + chunk_off(16 * rb + m, 4 * wv + q), relu4(acc[rb][0]));
+            for (int rb = 0; rb < NRB; ++rb) st4(tX[0] + chunk_off(16 * rb + m, 4 * wv + q), relu4(acc[rb][0]));
         }
         __syncthreads();
         if (wv < 2) {   // 64 -> 32, relu -> tX[1][:, 0:32]
-            f4 acc[3][1];
+            f4 acc[NRB][1];
             const f4 b = ld4(a.b2 + 16 * wv + 4 * q);
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b;
+            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
             float wf[1][16];
             load_wfrag<4>(a.w2, 64, 16 * wv, 0, 32, wf[0], lane);
-            mma_tile<4, 1>(tX[0], wf, acc, lane);
+            mma_tile<4, 1, 128, NRB>(tX[0], wf, acc, lane);
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) st4(tX[1] + chunk_off(16 * rb + m, 4 * wv + q), relu4(acc[rb][0]));
+            for (int rb = 0; rb < NRB; ++rb) st4(tX[1] + chunk_off(16 * rb + m, 4 * wv + q), relu4(acc[rb][0]));
         }
         __syncthreads();
         if (wv < 2) {   // 32 -> 21 (rows 21..31 of the weight read as zero) -> z in tX[2][:, 0:32]
-            f4 acc[3][1];
+            f4 acc[NRB][1];
             f4 b;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -101,12 +103,12 @@ __global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
                 b[r] = n < TMPNN_VOCAB ? a.b3[n] : 0.f;
             }
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b;
+            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
             float wf[1][8];
             load_wfrag<2>(a.w3, 32, 16 * wv, 0, TMPNN_VOCAB, wf[0], lane);
-            mma_tile<2, 1>(tX[1], wf, acc, lane);
+            mma_tile<2, 1, 128, NRB>(tX[1], wf, acc, lane);
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) st4(tX[2] + chunk_off(16 * rb + m, 4 * wv + q), acc[rb][0]);
+            for (int rb = 0; rb < NRB; ++rb) st4(tX[2] + chunk_off(16 * rb + m, 4 * wv + q), acc[rb][0]);
         }
         __syncthreads();
         for (int e = tid; e < rows * TMPNN_VOCAB; e += TM_THREADS) {
@@ -188,8 +190,22 @@ int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const 
                 float *z_opt, hipStream_t st) {
     HeadArgs a{w->conv_center, w->conv_b, w->mlp_w[0], w->mlp_b[0], w->mlp_w[1], w->mlp_b[1], w->mlp_w[2], w->mlp_b[2],
                w->ddg_w, w->ddg_b, w->Ws_w, hA, hB, S, ddg, z_opt, (int)T};
-    const int64_t tiles = (T + TM_TILE - 1) / TM_TILE, cap = tm_num_cus();
-    { tm_prof_begin("head", st); head_kernel<<<(int)(tiles < cap ? tiles : cap), TM_THREADS, 0, st>>>(a); tm_prof_end(st); }
+    // tile height for load balance, as in node_update: 1 workgroup per CU, ~1.2 MB of weights streamed per tile
+    const int64_t slots = tm_num_cus();
+    int best_rows = 48;
+    int64_t best_cost = -1;
+    for (int rows = 48; rows >= 16; rows -= 16) {
+        const int64_t tiles = (T + rows - 1) / rows, rounds = (tiles + slots - 1) / slots;
+        const int64_t cost = rounds * (rows + 16);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rows = rows; }
+    }
+    const int64_t tiles = (T + best_rows - 1) / best_rows;
+    const int grid = (int)(tiles < slots ? tiles : slots);
+    tm_prof_begin("head", st);
+    if (best_rows == 16) head_kernel<1><<<grid, TM_THREADS, 0, st>>>(a);
+    else if (best_rows == 32) head_kernel<2><<<grid, TM_THREADS, 0, st>>>(a);
+    else head_kernel<3><<<grid, TM_THREADS, 0, st>>>(a);
+    tm_prof_end(st);
     return tm_check_launch("ddg_head");
 }
 

@@ -125,9 +125,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void msg_kernel(MsgArgs a) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const int n = col0 + 16 * cb + 4 * q;
-            if (DEC) {
+            if (DEC) {   // the gathered terms ride in the accumulator: their L2 latency hides under the GEMM
 #pragma unroll
-                for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = f4{0.f, 0.f, 0.f, 0.f};
+                for (int rb = 0; rb < 3; ++rb)
+                    acc[rb][cb] = ld4(a.seq_table + a.S[jrow[rb]] * TM_H + n) + ld4(a.P + (size_t)jrow[rb] * 256 + 128 + n);
             } else {
                 const f4 ai = ld4(a.P + (size_t)i * 256 + n);
 #pragma unroll
@@ -143,10 +144,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void msg_kernel(MsgArgs a) {
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
                 f4 v = acc[rb][cb];
-                if (DEC) {
-                    const int j = jrow[rb];
-                    v = ai + mi * (v + ld4(a.seq_table + a.S[j] * TM_H + n) + ld4(a.P + (size_t)j * 256 + 128 + n));
-                }
+                if (DEC) v = ai + mi * v;
                 st4(tA + chunk_off(16 * rb + m, chunk0 + 4 * cb + q), gelu4(v));
             }
         }
@@ -1012,13 +1010,21 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
         a.proj[k] = ps[k] ? ProjSpec{ps[k]->Wa, ps[k]->lda, ps[k]->ba, ps[k]->Wc, ps[k]->ldc, ps[k]->P}
                           : ProjSpec{nullptr, 0, nullptr, nullptr, 0, nullptr};
     tm_prof_begin("node_update", st);
-    if (T < (int64_t)48 * tm_num_cus()) {       // small batch: 16-residue tiles spread one protein over 3x more CUs
-        const int64_t tiles = (T + 15) / 16;
-        node_update_kernel<1><<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a);
-    } else {
-        const int64_t tiles = (T + TM_TILE - 1) / TM_TILE;
-        node_update_kernel<3><<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a);
+    // Tile height (16 / 32 / 48 residues) chosen for load balance: the grid offers 2 workgroup slots per CU, every
+    // tile streams the same ~0.8 MB of weights from L2 (worth about 16 rows of MFMA time), so minimise
+    // rounds x (rows + 16). E.g. T = 16384: 48-row tiles = 342 tiles -> some CUs get 96 rows; 32-row tiles = exactly 512.
+    const int64_t slots = (int64_t)2 * tm_num_cus();
+    int best_rows = 48;
+    int64_t best_cost = -1;
+    for (int rows = 48; rows >= 16; rows -= 16) {
+        const int64_t tiles = (T + rows - 1) / rows, rounds = (tiles + slots - 1) / slots;
+        const int64_t cost = rounds * (rows + 16);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rows = rows; }
     }
+    const int64_t tiles = (T + best_rows - 1) / best_rows;
+    if (best_rows == 16) node_update_kernel<1><<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a);
+    else if (best_rows == 32) node_update_kernel<2><<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a);
+    else node_update_kernel<3><<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a);
     tm_prof_end(st);
     return tm_check_launch("node_update");
 }
