@@ -120,26 +120,38 @@ def gather_microbench(eng, device, n_nodes=16384, K=48, C_=128, iters=20):
             "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": nbytes / ms / 1e6 / copy_gbs}
 
 
-def cpu_baseline(batch, budget_s=12.0):
-    """The CPU oracle (oracle/thermompnn_oracle.py, kind 'port') on this box's host cores: full SSM of ONE
-    synthetic L=256 protein, vectorised head, repeated for ~budget_s seconds. Checker code, timed as a baseline."""
+def cpu_baseline(batch, budget_s=15.0):
+    """The CPU oracle (oracle/thermompnn_oracle.py, kind 'port') on this box's host cores: full SSM of ONE synthetic
+    L=256 protein, vectorised head (the oracle is the checker; here it is only timed, as a baseline). torch's default
+    thread count oversubscribes the small ops of a single protein, so a few thread counts share the budget and the best
+    one is reported with the number of threads it used."""
     from oracle import thermompnn_oracle as orc
     W = synthetic_state_dict(0)
     L = batch["L"]
     X = torch.tensor(batch["X_cpu"], dtype=torch.float32)[None]
     S = torch.tensor(batch["S_cpu"])[None]
     ones, ar = torch.ones(1, L), torch.arange(L)[None]
-    threads = torch.get_num_threads()
+    default_threads = torch.get_num_threads()
+    cands = sorted({default_threads, min(default_threads, 32), min(default_threads, 8)}, reverse=True)
+    tried, best = {}, None
     with torch.no_grad():
-        orc.ssm_table(W, X, S, ones, ones, ar, ones.long(), 48)          # warm-up
-        t0, reps = time.perf_counter(), 0
-        while time.perf_counter() - t0 < budget_s or reps < 3:
-            orc.ssm_table(W, X, S, ones, ones, ar, ones.long(), 48)
-            reps += 1
-        dt = time.perf_counter() - t0
-    return {"value": reps * L * 20 / dt, "unit": "preds/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x full SSM of one synthetic L={L} protein (5120 preds each), vectorised head, "
-                      f"torch CPU fp32, {dt:.1f} s"}
+        for nt in cands:
+            torch.set_num_threads(nt)
+            orc.ssm_table(W, X, S, ones, ones, ar, ones.long(), 48)          # warm-up
+            t0, reps = time.perf_counter(), 0
+            while time.perf_counter() - t0 < budget_s / len(cands) or reps < 2:
+                orc.ssm_table(W, X, S, ones, ones, ar, ones.long(), 48)
+                reps += 1
+            dt = time.perf_counter() - t0
+            tried[nt] = reps * L * 20 / dt
+            if best is None or tried[nt] > tried[best]:
+                best = nt
+                best_desc = (reps, dt)
+    torch.set_num_threads(default_threads)
+    return {"value": tried[best], "unit": "preds/s", "cores": best, "kind": "port",
+            "sample": f"{best_desc[0]} x full SSM of one synthetic L={L} protein (5120 preds each), vectorised head, torch CPU "
+                      f"fp32, {best_desc[1]:.1f} s at {best} threads (threads tried -> preds/s: "
+                      + ", ".join(f"{k}: {v:.0f}" for k, v in tried.items()) + ")"}
 
 
 def main():

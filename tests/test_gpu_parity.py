@@ -455,3 +455,63 @@ def test_centrality_and_baseline_and_scan(tmp_path, engine, synthetic_weights):
     ca0 = torch.tensor(full["coords_chain_A"]["CA_chain_A"])
     assert int(r["neighbors"]) == int(((torch.cdist(ca0, ca0) < 10.0).sum(-1) - 1)[17])
     assert int(rows[194 + 17]["neighbors"]) == int(want[17])     # second file = the gapped structure
+
+
+def _random_protein(rng, L, n_chains=1, p_missing=0.0):
+    from thermompnn_amd.synthetic import synthetic_backbone
+    X, seq = synthetic_backbone(L, int(rng.integers(1 << 30)))
+    S = np.array(["ACDEFGHIKLMNPQRSTVWY".index(c) for c in seq], dtype=np.int64)
+    mask = np.ones(L, np.float32)
+    miss = rng.random(L) < p_missing
+    mask[miss] = 0
+    X = X.astype(np.float32)
+    X[miss] = 0                                              # tied_featurize zeroes NaN coordinates
+    S[miss & (rng.random(L) < 0.5)] = 20                     # some of them are gaps ('X')
+    cuts = np.sort(rng.choice(np.arange(1, L), size=n_chains - 1, replace=False)) if n_chains > 1 and L > n_chains else []
+    chain = np.ones(L, np.int64)
+    for c in cuts:
+        chain[c:] += 1
+    ridx = 100 * (chain - 1) + np.arange(L)
+    return X, S, mask, ridx, chain
+
+
+@pytest.mark.parametrize("K", [48, 30])
+def test_randomised_parity_vs_oracle(K, synthetic_weights):
+    """Random lengths (1..120, many below K), random missing residues / gaps, 1-3 chains, K = 48 and K = 30: the fused
+    HIP forward vs the oracle run on the engine's (validated) neighbour graph."""
+    from oracle import thermompnn_oracle as orc
+    from thermompnn_amd.engine import Engine
+    eng = Engine(synthetic_weights, "cuda:0", K)
+    rng = np.random.default_rng(1234 + K)
+    prots = [_random_protein(rng, int(L), int(rng.integers(1, 4)), float(rng.choice([0.0, 0.05, 0.3])))
+             for L in [1, 2, 7, 31, 47, 48, 49, 64, 100, 120]]
+    lens = [len(p[1]) for p in prots]
+    cat = lambda k, dt: torch.tensor(np.concatenate([p[k] for p in prots])).to("cuda:0", dt)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
+    r = eng.ssm_forward(cat(0, torch.float32), cat(1, torch.int32), cat(2, torch.float32), cat(3, torch.int32),
+                        cat(4, torch.int32), offsets, want_hidden=True, want_log_probs=True, want_E_idx=True)
+    ddg, hid, lp, ei = (r[k].cpu().numpy() for k in ("ddg", "hidden", "log_probs", "E_idx"))
+    pos = 0
+    for (X, S, mask, ridx, chain), L in zip(prots, lens):
+        Keff = min(K, L)
+        blk = ei[pos:pos + L]
+        assert (blk[:, Keff:] == -1).all()
+        local = blk[:, :Keff] - pos
+        assert (local >= 0).all() and (local < L).all()
+        t = torch.from_numpy
+        D_adj = orc.adjusted_distances(t(X)[None, :, 1], t(mask)[None])[0].numpy()
+        for i in np.nonzero(mask > 0)[0]:                     # a valid top-k up to exact ties
+            kth = np.sort(D_adj[i])[Keff - 1]
+            assert (D_adj[i, local[i]] <= kth).all() and len(set(local[i].tolist())) == Keff
+        tr = {}
+        with torch.no_grad():
+            want = orc.ssm_table(synthetic_weights, t(X)[None], t(S)[None], t(mask)[None], torch.ones(1, L), t(ridx)[None],
+                                 t(chain)[None], K, trace=tr, E_idx_override=t(local.astype(np.int64))[None])[0].numpy()
+        valid = mask > 0
+        # rows that attend to a masked neighbour are implementation-defined in the reference only through WHICH masked
+        # residue ties in (SURVEY §7); with the graph pinned everything is comparable
+        np.testing.assert_allclose(hid[2, pos:pos + L][valid], tr["hV_dec3"][0].numpy()[valid], atol=2e-5, rtol=0)
+        np.testing.assert_allclose(lp[pos:pos + L][valid], tr["log_probs"][0].numpy()[valid], atol=2e-5, rtol=0)
+        np.testing.assert_allclose(ddg[pos:pos + L], want, atol=TOL_DDG, rtol=0)
+        assert (hid[:, pos:pos + L][:, ~valid] == 0).all()
+        pos += L
