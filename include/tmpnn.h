@@ -184,6 +184,10 @@ int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const float *P, f
                           int64_t T, int ablation, tmpnn_stream_t stream);
 int tmpnn_profile_fetch(const char **names, double *total_ms, int64_t *launches, int capacity);
 
+/* GEMM core probe: Y[t] = reps x (X[t] W^T) for T tiles of [48,128] and one [128,128] weight; mode 0 = exact fp32 MFMA,
+ * mode 1 = six-term bf16 split MFMA (tmpnn_bf3.h). For accuracy / speed comparisons of the two matrix-core paths. */
+int tmpnn_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, tmpnn_stream_t stream);
+
 /* Effective shader clock under a saturated fp32-MFMA stream (192 v_mfma_f32_16x16x4_f32 per iteration per wavefront,
  * 4 wavefronts per workgroup): out[2b] = shader cycles of workgroup b, out[2b+1] = the same interval in 100 MHz ticks.
  * `sink` (>= 256 floats) keeps the result live. */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "tmpnn_pdb_fill": (_i, [_p, _p, _p, _p, _p, _p, C.c_char_p]),
     "tmpnn_pdb_free": (None, [_p]),
     "tmpnn_profile_enable": (_i, [_i]),
+    "tmpnn_gemm_probe": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
     "tmpnn_clock_probe": (_i, [_i, _i, _p, _p, _p]),
     "tmpnn_ablate_enc_edge": (_i, [_p, _i, _p, _p, _p, _i64, _i, _p]),
     "tmpnn_profile_fetch": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), _i]),

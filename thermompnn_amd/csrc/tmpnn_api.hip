@@ -2,6 +2,7 @@
 // carving and the launch sequence of the fused forward. No device allocation, no stream sync.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -90,6 +91,11 @@ int tm_num_cus() {
         if (n <= 0) n = 256;
     }
     return n;
+}
+
+bool tm_use_bf3() {
+    static const bool v = [] { const char *e = getenv("TMPNN_PRECISION"); return e != nullptr && strcmp(e, "bf16x3") == 0; }();
+    return v;
 }
 
 extern "C" int tmpnn_version(void) { return TMPNN_VERSION; }
@@ -395,6 +401,12 @@ extern "C" int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const 
                                      int64_t T, int ablation, tmpnn_stream_t stream) {
     REQUIRE(w && P && h_E && E_idx && layer >= 0 && layer < 3 && T > 0 && T <= T_MAX, "ablate_enc_edge: bad argument");
     return launch_enc_edge(w->enc[layer], P, h_E, E_idx, T, (hipStream_t)stream, ablation);
+}
+
+// measurement hook (tools/gemm_probe.py): one [48x128] x [128x128]^T GEMM per tile, mode 0 = fp32 MFMA, 1 = six-term bf16 MFMA
+extern "C" int tmpnn_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, tmpnn_stream_t stream) {
+    REQUIRE(X && W && Y && T > 0 && reps > 0 && (mode == 0 || mode == 1), "gemm_probe: bad argument");
+    return launch_gemm_probe(mode, X, W, Y, T, reps, (hipStream_t)stream);
 }
 
 // measurement hook: effective shader clock under a saturated fp32-MFMA load; out[2b] = shader cycles, out[2b+1] = 100 MHz ticks

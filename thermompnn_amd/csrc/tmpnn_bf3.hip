@@ -1,0 +1,207 @@
+// Split-precision (bf16 x 3, six-term) forms of the per-edge kernels. See tmpnn_bf3.h for the arithmetic.
+#include <stdlib.h>
+
+#include "tmpnn_bf3.h"
+#include "tmpnn_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// GEMM probe (tools/gemm_probe.py): Y[t] = X[t] W^T per 48 x 128 tile, fp32 MFMA vs six-term bf16 MFMA, 8 wavefronts
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_probe_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                            float *__restrict__ Y, int T, int reps) {
+    __shared__ __attribute__((aligned(16))) float tF[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) char tP[BF3_TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    float wf[1][32];
+    WFrag3 w3[1][4];
+    if (MODE == 0) load_wfrag<8>(W, TM_H, 16 * wv, 0, TM_H, wf[0], lane);
+    else load_wfrag_bf3<4>(W, TM_H, 16 * wv, 0, TM_H, w3[0], lane);
+    for (int i = blockIdx.x; i < T; i += gridDim.x) {
+        const float *src = X + (size_t)i * TM_TILE * TM_H;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = it * 512 + tid, row = idx >> 5, c = idx & 31;
+            const f4 v = ld4(src + (size_t)idx * 4);
+            if (MODE == 0) st4(tF + chunk_off(row, c), v);
+            else store_split(tP, row, c, v);
+        }
+        __syncthreads();
+        f4 acc[3][1];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < reps; ++r) {
+            if (MODE == 0) mma_tile<8, 1>(tF, wf, acc, lane);
+            else mma_tile_bf3<4, 1>(tP, w3, acc, lane);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+            st4(Y + ((size_t)i * TM_TILE + 16 * rb + m) * TM_H + 16 * wv + 4 * q, acc[rb][0]);
+        __syncthreads();
+    }
+}
+
+int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, hipStream_t st) {
+    const int64_t cap = tm_num_cus();
+    const int grid = (int)(T < cap ? T : cap);
+    if (mode == 0) gemm_probe_kernel<0><<<grid, 512, 0, st>>>(X, W, Y, (int)T, reps);
+    else gemm_probe_kernel<1><<<grid, 512, 0, st>>>(X, W, Y, (int)T, reps);
+    return tm_check_launch("gemm_probe");
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// enc_edge, split-precision form (8 wavefronts, 1 workgroup per CU): same pipeline as enc_edge8_kernel
+// (tmpnn_layers.hip) with the three 128x128 GEMMs on the bf16 matrix cores. GEMM inputs live in LDS as plane tiles;
+// the residual re-joins the planes exactly (x = h + m + l); the LayerNorm input is an fp32 tile aliased on the x planes.
+// The next residue's tile is prefetched into registers at the top of the iteration and split into the e planes
+// during the LayerNorm/store phase.
+// ------------------------------------------------------------------------------------------------
+struct EdgeArgsB {
+    const float *W11e, *W12, *b12, *W13, *b13, *g3, *be3, *P;
+    float *hE;
+    const int32_t *E_idx;
+    int T;
+};
+
+__device__ __forceinline__ void row_stats_partial1b(const f4 v, float *stat_slot, int q) {
+    float mean = (v.x + v.y + v.z + v.w) * 0.25f;
+    const f4 d = v - mean;
+    float m2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    float n = 4.f;
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float mo = __shfl_xor(mean, off), m2o = __shfl_xor(m2, off);
+        const float delta = mo - mean;
+        mean = 0.5f * (mean + mo);
+        m2 = m2 + m2o + delta * delta * (0.5f * n);
+        n *= 2.f;
+    }
+    if (q == 0) { stat_slot[0] = mean; stat_slot[1] = m2; }
+}
+__device__ __forceinline__ void row_stats_finish8b(const float *stat_row, float &mean, float &rstd) {
+    f4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = ld4(stat_row + 4 * k);
+    mean = 0.125f * (p[0].x + p[0].z + p[1].x + p[1].z + p[2].x + p[2].z + p[3].x + p[3].z);
+    float m2 = 0.f, dd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float d0 = p[k].x - mean, d1 = p[k].z - mean;
+        m2 += p[k].y + p[k].w;
+        dd += d0 * d0 + d1 * d1;
+    }
+    rstd = 1.0f / sqrtf((m2 + 16.f * dd) * (1.0f / 128.0f) + 1e-5f);
+}
+
+__global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
+    __shared__ __attribute__((aligned(16))) char tE[BF3_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char tX[BF3_TILE_BYTES];     // x planes; later the fp32 LayerNorm input
+    __shared__ __attribute__((aligned(16))) char tY[BF3_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
+    __shared__ int s_idx[2][TM_TILE];
+    float *tO = reinterpret_cast<float *>(tX);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+
+    WFrag3 w11[1][4], w12[1][4], w13[1][4];
+    load_wfrag_bf3<4>(a.W11e, 384, 16 * wv, 0, TM_H, w11[0], lane);
+    load_wfrag_bf3<4>(a.W12, TM_H, 16 * wv, 0, TM_H, w12[0], lane);
+    load_wfrag_bf3<4>(a.W13, TM_H, 16 * wv, 0, TM_H, w13[0], lane);
+    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
+    const f4 b12 = ld4(a.b12 + ncol), b13 = ld4(a.b13 + ncol);
+    const int c32 = lane & 31;
+    const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
+
+    const TileRange tr = xcd_tile_range(a.T);
+    int i = tr.begin;
+    int cur = 0;
+    f4 gai, gcj[3];
+    if (i < tr.end) {
+        if (tid < TM_TILE) s_idx[0][tid] = a.E_idx[(size_t)i * TM_KS + tid];
+        const float *src = a.hE + (size_t)i * TM_KS * TM_H;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = it * 512 + tid;
+            store_split(tE, idx >> 5, idx & 31, ld4(src + (size_t)idx * 4));
+        }
+        __syncthreads();
+        gai = ld4(a.P + (size_t)i * 256 + ncol);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int j = s_idx[0][16 * rb + m];
+            gcj[rb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol);
+        }
+    }
+    for (; i < tr.end; i += tr.step) {
+        float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
+        const int inext = i + tr.step;
+        const bool has_next = inext < tr.end;
+        f4 pre[3];
+        int nidx = -1;
+        if (has_next) {
+            const float *src = a.hE + (size_t)inext * TM_KS * TM_H;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) pre[it] = ld4(src + (size_t)(it * 512 + tid) * 4);
+            if (tid < TM_TILE) nidx = a.E_idx[(size_t)inext * TM_KS + tid];
+        }
+        f4 acc[3][1];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
+        mma_tile_bf3<4, 1>(tE, w11, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) store_split(tX, 16 * rb + m, c4, gelu4(acc[rb][0]));
+        if (has_next && tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx;
+        __syncthreads();
+
+        if (has_next) {
+            gai = ld4(a.P + (size_t)inext * 256 + ncol);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                const int j = s_idx[cur ^ 1][16 * rb + m];
+                gcj[rb] = ld4(a.P + (size_t)(j < 0 ? inext : j) * 256 + 128 + ncol);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
+        mma_tile_bf3<4, 1>(tX, w12, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) store_split(tY, 16 * rb + m, c4, gelu4(acc[rb][0]));
+        __syncthreads();
+
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
+        mma_tile_bf3<4, 1>(tY, w13, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const f4 v = load_joined(tE, 16 * rb + m, c4) + acc[rb][0];     // residual (exact re-join of e)
+            st4(tO + chunk_off(16 * rb + m, c4), v);
+            row_stats_partial1b(v, &s_stat[16 * rb + m][2 * wv], q);
+        }
+        __syncthreads();                                                     // tE free, tO + stats complete
+
+        if (has_next) {
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int idx = it * 512 + tid;
+                store_split(tE, idx >> 5, idx & 31, pre[it]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int row = 6 * wv + 2 * it + (lane >> 5);
+            float mean, rstd;
+            row_stats_finish8b(&s_stat[row][0], mean, rstd);
+            const f4 y = (ld4(tO + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
+            if (s_idx[cur][row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
+int launch_enc_edge_bf3(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
+    EdgeArgsB a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
+    const int64_t cap = tm_num_cus();
+    enc_edge8_bf3_kernel<<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
+    return tm_check_launch("enc_edge_bf3");
+}

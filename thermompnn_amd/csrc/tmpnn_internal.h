@@ -76,4 +76,9 @@ int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float 
 int launch_prep_tables(tmpnn_weights *w, hipStream_t st);
 
 int launch_clock_probe(int blocks, int iters, unsigned long long *out, float *sink, hipStream_t st);
+// tmpnn_bf3.hip
+int launch_enc_edge_bf3(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
+int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, hipStream_t st);
+
 int tm_num_cus();
+bool tm_use_bf3();     // TMPNN_PRECISION=bf16x3 (default) | fp32: matrix-core path of the per-edge GEMMs

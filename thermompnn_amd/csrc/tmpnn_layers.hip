@@ -971,7 +971,12 @@ int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_i
     // selectable for experiments: TMPNN_ENC_EDGE_VARIANT = 1 (4-wavefront), 16 (ping-pong), 64 (2 workgroups per CU),
     // or the ablation codes of tmpnn_ablate_enc_edge (0 there means the 4-wavefront kernel).
     static const int variant = [] { const char *e = getenv("TMPNN_ENC_EDGE_VARIANT"); return e ? atoi(e) : 32; }();
-    if (abl < 0) abl = variant == 1 ? 0 : variant;
+    if (abl < 0) abl = tm_use_bf3() ? 128 : (variant == 1 ? 0 : variant);
+    if (abl == 128) {      // split-precision bf16 matrix-core form (tmpnn_bf3.hip)
+        const int rc = launch_enc_edge_bf3(e, P, hE, E_idx, T, st);
+        tm_prof_end(st);
+        return rc;
+    }
     if (abl == 64) {
         enc_edge2_kernel<<<grid_for(T, 2), TM_THREADS, 0, st>>>(a);
         tm_prof_end(st);

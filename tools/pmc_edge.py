@@ -10,11 +10,10 @@ g = torch.Generator().manual_seed(0)
 P = torch.randn(T, 256, generator=g).cuda(); hE0 = torch.randn(T, 48, 128, generator=g).cuda()
 E_idx = ((torch.arange(T) // 256 * 256)[:, None] + torch.randint(0, 256, (T, 48), generator=g)).int().cuda()
 outs = {}
-for abl in (0, 16, 32, 7, 8):
+for abl in (0, 32, 128):
     for rep in range(3):
         x = hE0.clone()
         assert lib.tmpnn_ablate_enc_edge(eng.w.handle, 0, _ptr(P), _ptr(x), _ptr(E_idx), T, abl, _stream()) == 0
     torch.cuda.synchronize()
     outs[abl] = x
-print("pp == classic:", torch.equal(outs[0], outs[16]), " 8-wave == classic:", torch.equal(outs[0], outs[32]),
-      float((outs[0] - outs[32]).abs().max()))
+print("max diff 8-wave vs bf3:", float((outs[32] - outs[128]).abs().max()))
