@@ -61,32 +61,33 @@ __device__ __forceinline__ void split3_f4(f4 v, u2 &ph, u2 &pm, u2 &pl) {
     pl = u2{l0, l1};
 }
 
-// byte offset inside a plane tile of columns [4*c4, 4*c4+4) of row `row`, plane p   (c4 = 0..31)
-template <int ROWS = TM_TILE>
+// byte offset inside a plane tile of columns [4*c4, 4*c4+4) of row `row`, plane p. ROWB = bytes per plane row
+// (256 for the 128-column tiles, 512 for the featurizer's half-width RBF tiles), ROWS = rows per plane.
+template <int ROWS = TM_TILE, int ROWB = 256>
 __device__ __forceinline__ int plane_off4(int p, int row, int c4) {
-    return p * (ROWS * TM_H * 2) + row * 256 + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3));
+    return p * (ROWS * ROWB) + row * ROWB + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3));
 }
 // byte offset of the 16-byte chunk c16 (columns [8*c16, 8*c16+8)) of row `row`, plane p
-template <int ROWS = TM_TILE>
+template <int ROWS = TM_TILE, int ROWB = 256>
 __device__ __forceinline__ int plane_off8(int p, int row, int c16) {
-    return p * (ROWS * TM_H * 2) + row * 256 + ((c16 ^ (row & 15)) << 4);
+    return p * (ROWS * ROWB) + row * ROWB + ((c16 ^ (row & 15)) << 4);
 }
 
 // write four consecutive fp32 columns of one row into the three planes
-template <int ROWS = TM_TILE>
+template <int ROWS = TM_TILE, int ROWB = 256>
 __device__ __forceinline__ void store_split(char *tile, int row, int c4, f4 v) {
     u2 ph, pm, pl;
     split3_f4(v, ph, pm, pl);
-    *reinterpret_cast<u2 *>(tile + plane_off4<ROWS>(0, row, c4)) = ph;
-    *reinterpret_cast<u2 *>(tile + plane_off4<ROWS>(1, row, c4)) = pm;
-    *reinterpret_cast<u2 *>(tile + plane_off4<ROWS>(2, row, c4)) = pl;
+    *reinterpret_cast<u2 *>(tile + plane_off4<ROWS, ROWB>(0, row, c4)) = ph;
+    *reinterpret_cast<u2 *>(tile + plane_off4<ROWS, ROWB>(1, row, c4)) = pm;
+    *reinterpret_cast<u2 *>(tile + plane_off4<ROWS, ROWB>(2, row, c4)) = pl;
 }
 // exact reconstruction x = h + m + l of four consecutive columns
-template <int ROWS = TM_TILE>
+template <int ROWS = TM_TILE, int ROWB = 256>
 __device__ __forceinline__ f4 load_joined(const char *tile, int row, int c4) {
-    const u2 ph = *reinterpret_cast<const u2 *>(tile + plane_off4<ROWS>(0, row, c4));
-    const u2 pm = *reinterpret_cast<const u2 *>(tile + plane_off4<ROWS>(1, row, c4));
-    const u2 pl = *reinterpret_cast<const u2 *>(tile + plane_off4<ROWS>(2, row, c4));
+    const u2 ph = *reinterpret_cast<const u2 *>(tile + plane_off4<ROWS, ROWB>(0, row, c4));
+    const u2 pm = *reinterpret_cast<const u2 *>(tile + plane_off4<ROWS, ROWB>(1, row, c4));
+    const u2 pl = *reinterpret_cast<const u2 *>(tile + plane_off4<ROWS, ROWB>(2, row, c4));
     f4 v;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -130,9 +131,9 @@ __device__ __forceinline__ void load_wfrag_bf3(const float *__restrict__ W, int 
 
 // acc[rb][cb] += W_cb . tile^T over K = 32*NK32 with the six-term split product. The low-order terms go through a
 // second accumulator that is folded in at the end, so they are not swamped while the leading term is still growing.
-// CHUNK0 = first 16-byte chunk (of 8 columns) of the tile row to start from (K sub-ranges of wider tiles).
-template <int NK32, int NCB, int NRB = 3, int ROWS = TM_TILE>
-__device__ __forceinline__ void mma_tile_bf3(const char *tile, const WFrag3 (&w)[NCB][NK32], f4 (&acc)[NRB][NCB], int lane) {
+// The weight fragments used are w[cb][C0 .. C0+NK32) (a K sub-range of a wider weight); the tile starts at its column 0.
+template <int NK32, int NCB, int NRB = 3, int ROWS = TM_TILE, int ROWB = 256, int NKTOT = NK32, int C0 = 0>
+__device__ __forceinline__ void mma_tile_bf3(const char *tile, const WFrag3 (&w)[NCB][NKTOT], f4 (&acc)[NRB][NCB], int lane) {
     const int m = lane & 15, q = lane >> 4;
     f4 lo[NRB][NCB];
 #pragma unroll
@@ -146,12 +147,12 @@ __device__ __forceinline__ void mma_tile_bf3(const char *tile, const WFrag3 (&w)
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                x[rb][p] = *reinterpret_cast<const bf8 *>(tile + plane_off8<ROWS>(p, 16 * rb + m, 4 * c + q));
+                x[rb][p] = *reinterpret_cast<const bf8 *>(tile + plane_off8<ROWS, ROWB>(p, 16 * rb + m, 4 * c + q));
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                const WFrag3 &wf = w[cb][c];
+                const WFrag3 &wf = w[cb][C0 + c];
                 lo[rb][cb] = mfma_bf16(wf.p[2], x[rb][0], lo[rb][cb]);   // l h
                 lo[rb][cb] = mfma_bf16(wf.p[0], x[rb][2], lo[rb][cb]);   // h l
                 lo[rb][cb] = mfma_bf16(wf.p[1], x[rb][1], lo[rb][cb]);   // m m

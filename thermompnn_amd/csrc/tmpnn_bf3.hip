@@ -205,3 +205,139 @@ int launch_enc_edge_bf3(const EncW &e, const float *P, float *hE, const int32_t 
     enc_edge8_bf3_kernel<<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
     return tm_check_launch("enc_edge_bf3");
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// message kernels, split-precision form (8 wavefronts, 1 workgroup per CU, next tile prefetched through registers).
+// Same arithmetic as msg_kernel (tmpnn_layers.hip): Ssum_i = sum_k ma_ik gelu(W2 gelu(pre_ik) + b2).
+// ------------------------------------------------------------------------------------------------
+struct MsgArgsB {
+    const float *W1e; int ld1;
+    const float *W2, *b2, *P, *seq_table;
+    const int32_t *S;
+    const float *hE;
+    const int32_t *E_idx;
+    const float *mask;
+    float *Ssum, *cnt;
+    int T;
+};
+
+template <bool DEC>
+__global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
+    __shared__ __attribute__((aligned(16))) char tE[BF3_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char tA[BF3_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float tS[TM_TILE * TM_H];
+    __shared__ float s_part[3][TM_H];
+    __shared__ int s_idx[2][TM_TILE];
+    __shared__ float s_ma[2][TM_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+
+    WFrag3 w1[1][4], w2[1][4];
+    load_wfrag_bf3<4>(a.W1e, a.ld1, 16 * wv, 0, TM_H, w1[0], lane);
+    load_wfrag_bf3<4>(a.W2, TM_H, 16 * wv, 0, TM_H, w2[0], lane);
+    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
+    const f4 bias2 = ld4(a.b2 + ncol);
+
+    const TileRange tr = xcd_tile_range(a.T);
+    int i = tr.begin;
+    int cur = 0;
+    f4 g0, gj[3];                       // node terms of the tile about to be processed (see gather())
+    auto stage_idx = [&](int ii, int buf) {       // neighbour list + attention mask of residue ii -> LDS
+        if (tid < TM_TILE) {
+            const int j = a.E_idx[(size_t)ii * TM_KS + tid];
+            s_idx[buf][tid] = j;
+            s_ma[buf][tid] = j < 0 ? 0.f : (DEC ? 1.f : a.mask[ii] * a.mask[j]);
+        }
+    };
+    auto gather = [&](int ii, int buf) {
+        g0 = ld4(a.P + (size_t)ii * 256 + ncol);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int j0 = s_idx[buf][16 * rb + m];
+            const int j = j0 < 0 ? ii : j0;
+            gj[rb] = ld4(a.P + (size_t)j * 256 + 128 + ncol);
+            if (DEC) gj[rb] += ld4(a.seq_table + a.S[j] * TM_H + ncol);
+        }
+    };
+    if (i < tr.end) {
+        stage_idx(i, 0);
+        const float *src = a.hE + (size_t)i * TM_KS * TM_H;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = it * 512 + tid;
+            store_split(tE, idx >> 5, idx & 31, ld4(src + (size_t)idx * 4));
+        }
+        __syncthreads();
+        gather(i, 0);
+    }
+    for (; i < tr.end; i += tr.step) {
+        const int inext = i + tr.step;
+        const bool has_next = inext < tr.end;
+        const float mi = a.mask[i];
+        f4 pre[3];
+        if (has_next) {
+            const float *src = a.hE + (size_t)inext * TM_KS * TM_H;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) pre[it] = ld4(src + (size_t)(it * 512 + tid) * 4);
+            stage_idx(inext, cur ^ 1);
+        }
+        f4 acc[3][1];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
+        mma_tile_bf3<4, 1>(tE, w1, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            f4 v = acc[rb][0];
+            if (DEC) v = g0 + mi * v;
+            store_split(tA, 16 * rb + m, c4, gelu4(v));
+        }
+        __syncthreads();                                         // tE consumed; tA, s_idx/s_ma[next] complete
+
+        if (has_next) {
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int idx = it * 512 + tid;
+                store_split(tE, idx >> 5, idx & 31, pre[it]);
+            }
+            gather(inext, cur ^ 1);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = bias2;
+        mma_tile_bf3<4, 1>(tA, w2, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const float ma = s_ma[cur][16 * rb + m];
+            f4 v = gelu4(acc[rb][0]) * ma;
+            if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
+            st4(tS + chunk_off(16 * rb + m, c4), v);
+        }
+        __syncthreads();
+        {   // per-node aggregation: column sums over 4 row groups of 12, combined in a fixed order
+            const int n = tid & 127, grp = tid >> 7;
+            float s = 0.f;
+#pragma unroll
+            for (int r = 12 * grp; r < 12 * grp + 12; ++r) s += tS[chunk_off(r, n >> 2) + (n & 3)];
+            if (grp) s_part[grp - 1][n] = s;
+            __syncthreads();
+            if (!grp) a.Ssum[(size_t)i * TM_H + n] = ((s + s_part[0][n]) + s_part[1][n]) + s_part[2][n];
+            if (tid == 128) {
+                float c = 0.f;
+                for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
+                a.cnt[i] = c;
+            }
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
+int launch_msg_bf3(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
+                   const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
+                   int64_t T, float *Ssum, float *cnt, hipStream_t st) {
+    MsgArgsB a{W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, Ssum, cnt, (int)T};
+    const int64_t cap = tm_num_cus();
+    const int grid = (int)(T < cap ? T : cap);
+    if (dec) msg8_bf3_kernel<true><<<grid, 512, 0, st>>>(a);
+    else msg8_bf3_kernel<false><<<grid, 512, 0, st>>>(a);
+    return tm_check_launch(dec ? "dec_msg_bf3" : "enc_msg_bf3");
+}

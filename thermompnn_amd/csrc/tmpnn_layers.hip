@@ -952,6 +952,12 @@ int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float
     static const int nw = [] { const char *e = getenv("TMPNN_MSG_WAVES"); return e ? atoi(e) : 4; }();
     const int grid = grid_for(T, 2);
     tm_prof_begin(dec ? "dec_msg" : "enc_msg", st);
+    static const bool msg_bf3 = [] { const char *e = getenv("TMPNN_MSG_BF3"); return e == nullptr || e[0] != '0'; }();
+    if (tm_use_bf3() && msg_bf3) {
+        const int rc = launch_msg_bf3(dec, W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, T, Ssum, cnt, st);
+        tm_prof_end(st);
+        return rc;
+    }
     if (nw == 8) {
         if (dec) msg_kernel<true, 8><<<grid, 512, 0, st>>>(a);
         else msg_kernel<false, 8><<<grid, 512, 0, st>>>(a);
