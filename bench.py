@@ -30,6 +30,7 @@ from thermompnn_amd.weights import synthetic_state_dict  # noqa: E402
 
 AA20 = "ACDEFGHIKLMNPQRSTVWY"
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
 
 
@@ -233,7 +234,8 @@ def main():
                                "full 20xL SSM each, inputs resident in HBM" +
                                ("; per-step RCCL all-gather of ddG tables" if world > 1 else ""),
                    "proteins_per_gpu": B, "L": L, "K": 48, "h": 128, "preds_per_step": preds_per_step,
-                   "weights": "synthetic_state_dict(seed=0)", "parallelism": f"proteins sharded x{world}"},
+                   "weights": "synthetic_state_dict(seed=0)", "parallelism": f"proteins sharded x{world}",
+                   "matmul": lib.tmpnn_matmul_mode().decode() + " (per-edge GEMMs; TMPNN_PRECISION=fp32 selects exact fp32 MFMA)"},
     }
 
     if rank == 0:
@@ -243,8 +245,16 @@ def main():
             dom = max(kern, key=lambda k: kern[k]["total_ms"])
             fl = kernel_flops(dom, T, edges)
             achieved = fl / (kern[dom]["avg_ms"] * 1e-3) / 1e12
+            mode = lib.tmpnn_matmul_mode().decode()
+            split = mode == "bf16x3" and dom in ("enc_edge", "enc_msg", "dec_msg")
             result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom, T), "kernel": dom,
+                                  "note": ("algorithmic fp32 flops against the fp32 MFMA peak (the problem is an fp32 GEMM chain); "
+                                           "this kernel executes them as six-term bf16x3 split products on the bf16 matrix cores "
+                                           "(see 'executed')" if split else "exact fp32 MFMA"),
+                                  "executed": ({"dtype": "bf16", "flops_per_launch": 6 * fl, "achieved": 6 * achieved,
+                                                "peak": BF16_MFMA_PEAK_TFLOPS, "frac": 6 * achieved / BF16_MFMA_PEAK_TFLOPS}
+                                               if split else None),
                                   "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_traffic.json)",
                                   "flops_per_launch": fl, "avg_launch_ms": kern[dom]["avg_ms"],
                                   "timed_with": "hipEvent pairs on the launch stream inside the timed region"}

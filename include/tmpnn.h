@@ -50,6 +50,11 @@ typedef void *tmpnn_stream_t;                   /* hipStream_t */
 
 int tmpnn_version(void);
 const char *tmpnn_last_error(void);
+/* "bf16x3" (default) or "fp32": how the per-edge 128x128 GEMMs of the message / edge-update kernels run on the matrix
+ * cores. bf16x3 = every fp32 operand split exactly into three bf16 values, six partial products per term on
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-class accuracy, ~2.2x the fp32-MFMA GEMM rate); fp32 = exact
+ * v_mfma_f32_16x16x4_f32. Selected once per process by the environment variable TMPNN_PRECISION. */
+const char *tmpnn_matmul_mode(void);
 
 /* ---- weights ------------------------------------------------------------------------------------
  * Canonical tensor order = the reference state dict: the 118 ProteinMPNN tensors in module

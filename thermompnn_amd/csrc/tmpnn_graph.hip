@@ -384,13 +384,9 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
         a.mu[i] = i < 8 ? (float)(2.0 + (20.0 / 15.0) * i) : (float)(22.0 - (20.0 / 15.0) * (15 - i));
     const int64_t cap = tm_num_cus();
     static const int nw = [] { const char *e = getenv("TMPNN_FEAT_WAVES"); return e ? atoi(e) : 8; }();
-    static const bool feat_bf3 = [] { const char *e = getenv("TMPNN_FEAT_BF3"); return e != nullptr && e[0] == '1'; }();   // measured: no faster than fp32
+    // (a split-precision bf16x3 form of this kernel was measured and dropped: the Gaussian generation + plane splitting
+    //  and its two extra barriers cost as much as the shorter 400->128 GEMM saved; 1.07 vs 1.08 ms)
     tm_prof_begin("featurize", st);
-    if (tm_use_bf3() && feat_bf3) {
-        const int rc = launch_featurize_bf3(w, X, ridx, cenc, E_idx, D_nb, T, h_E, E_opt, st);
-        tm_prof_end(st);
-        return rc;
-    }
     if (nw == 4) featurize_kernel<4><<<(int)(T < cap ? T : cap), 256, 0, st>>>(a);
     else featurize_kernel<8><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
     tm_prof_end(st);

@@ -81,8 +81,6 @@ int launch_enc_edge_bf3(const EncW &e, const float *P, float *hE, const int32_t 
 int launch_msg_bf3(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                    const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
                    int64_t T, float *Ssum, float *cnt, hipStream_t st);
-int launch_featurize_bf3(const tmpnn_weights *w, const float *X, const int32_t *ridx, const int32_t *cenc,
-                         const int32_t *E_idx, const float *D_nb, int64_t T, float *h_E, float *E_opt, hipStream_t st);
 int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, hipStream_t st);
 
 int tm_num_cus();
