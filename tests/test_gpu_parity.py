@@ -529,3 +529,23 @@ def test_both_matmul_modes_pass_golden_parity(mode):
             % (os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0], os.path.dirname(GOLDEN), mode, __file__))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_split_precision_gemm_core_accuracy():
+    """The six-term bf16x3 matrix-core GEMM is at least as accurate as the exact-fp32 MFMA chain (vs float64)."""
+    from thermompnn_amd import _lib
+    from thermompnn_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    T = 64
+    g = torch.Generator().manual_seed(5)
+    X = (torch.randn(T, 48, 128, generator=g) * torch.logspace(-3, 2, 128)).cuda()      # 5 decades of column scales
+    W = (torch.rand(128, 128, generator=g) * 0.4 - 0.2).cuda()
+    ref = X.double() @ W.double().t()
+    scale = (X.double().abs() @ W.double().abs().t())                                   # error is relative to sum |a||b|
+    errs = {}
+    for mode in (0, 1):
+        Y = torch.zeros_like(X)
+        assert lib.tmpnn_gemm_probe(mode, _ptr(X), _ptr(W), _ptr(Y), T, 1, _stream()) == 0
+        torch.cuda.synchronize()
+        errs[mode] = float(((Y.double() - ref).abs() / scale).max())
+    assert errs[1] < 4e-7 and errs[1] <= 1.5 * errs[0], errs

@@ -176,3 +176,20 @@ def test_retrieve_best_mutants_and_rows():
     assert set(rows[0]) == set(COLUMNS)
     best = rows_for_protein(p, t, None, "ThermoMPNN", "ds", pick_best=True, include_cys=True)
     assert [(r["position"], r["mutation"], r["best_AA"]) for r in best] == [(0, "A", "C"), (2, "A", "E")]
+
+
+def test_metrics_match_scipy():
+    from scipy import stats
+    from thermompnn_amd.metrics import get_metrics
+    rng = np.random.default_rng(0)
+    t = rng.normal(size=500)
+    p = 0.7 * t + 0.5 * rng.normal(size=500)
+    p[::50] = p[1::50]                                   # ties
+    t[3] = np.nan
+    m = get_metrics(p, t)
+    ok = np.isfinite(t)
+    assert m["n"] == 499
+    assert abs(m["pearson"] - stats.pearsonr(p[ok], t[ok])[0]) < 1e-12
+    assert abs(m["spearman"] - stats.spearmanr(p[ok], t[ok])[0]) < 1e-12
+    assert abs(m["rmse"] - np.sqrt(np.mean((p[ok] - t[ok]) ** 2))) < 1e-12
+    assert abs(m["r2"] - (1 - ((p[ok] - t[ok]) ** 2).sum() / ((t[ok] - t[ok].mean()) ** 2).sum())) < 1e-12
