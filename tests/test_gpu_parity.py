@@ -549,3 +549,26 @@ def test_split_precision_gemm_core_accuracy():
         torch.cuda.synchronize()
         errs[mode] = float(((Y.double() - ref).abs() / scale).max())
     assert errs[1] < 4e-7 and errs[1] <= 1.5 * errs[0], errs
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the contract's keys (tiny workload; no CPU baseline leg)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--proteins-per-gpu", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "preds/s" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 2 * 256 * 20 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert d["roofline_gather"]["bound"] == "hbm" and d["roofline_gather"]["unit"] == "GB/s"
