@@ -142,24 +142,23 @@ __device__ __forceinline__ void mma_tile_bf3(const char *tile, const WFrag3 (&w)
         for (int cb = 0; cb < NCB; ++cb) lo[rb][cb] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NK32; ++c) {
-        bf8 x[NRB][3];
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+        for (int rb = 0; rb < NRB; ++rb) {
+            bf8 x[3];                                  // one row block at a time: 12 VGPRs of B fragments in flight
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                x[rb][p] = *reinterpret_cast<const bf8 *>(tile + plane_off8<ROWS, ROWB>(p, 16 * rb + m, 4 * c + q));
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+                x[p] = *reinterpret_cast<const bf8 *>(tile + plane_off8<ROWS, ROWB>(p, 16 * rb + m, 4 * c + q));
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const WFrag3 &wf = w[cb][C0 + c];
-                lo[rb][cb] = mfma_bf16(wf.p[2], x[rb][0], lo[rb][cb]);   // l h
-                lo[rb][cb] = mfma_bf16(wf.p[0], x[rb][2], lo[rb][cb]);   // h l
-                lo[rb][cb] = mfma_bf16(wf.p[1], x[rb][1], lo[rb][cb]);   // m m
-                lo[rb][cb] = mfma_bf16(wf.p[1], x[rb][0], lo[rb][cb]);   // m h
-                lo[rb][cb] = mfma_bf16(wf.p[0], x[rb][1], lo[rb][cb]);   // h m
-                acc[rb][cb] = mfma_bf16(wf.p[0], x[rb][0], acc[rb][cb]); // h h
+                lo[rb][cb] = mfma_bf16(wf.p[2], x[0], lo[rb][cb]);   // l h
+                lo[rb][cb] = mfma_bf16(wf.p[0], x[2], lo[rb][cb]);   // h l
+                lo[rb][cb] = mfma_bf16(wf.p[1], x[1], lo[rb][cb]);   // m m
+                lo[rb][cb] = mfma_bf16(wf.p[1], x[0], lo[rb][cb]);   // m h
+                lo[rb][cb] = mfma_bf16(wf.p[0], x[1], lo[rb][cb]);   // h m
+                acc[rb][cb] = mfma_bf16(wf.p[0], x[0], acc[rb][cb]); // h h
             }
+        }
     }
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
     __shared__ __attribute__((aligned(16))) char tE[BF3_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) char tX[BF3_TILE_BYTES];     // x planes; later the fp32 LayerNorm input
     __shared__ __attribute__((aligned(16))) char tY[BF3_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float tStage[TM_TILE * TM_H]; // next residue's fp32 tile, landed by LDS-DMA
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
     __shared__ int s_idx[2][TM_TILE];
     float *tO = reinterpret_cast<float *>(tX);
@@ -108,9 +109,24 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
     load_wfrag_bf3<4>(a.W12, TM_H, 16 * wv, 0, TM_H, w12[0], lane);
     load_wfrag_bf3<4>(a.W13, TM_H, 16 * wv, 0, TM_H, w13[0], lane);
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
-    const f4 b12 = ld4(a.b12 + ncol), b13 = ld4(a.b13 + ncol);
     const int c32 = lane & 31;
-    const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
+
+    // linear (unswizzled) LDS-DMA of one fp32 tile: 24 wave-instructions of 1 KB, three per wavefront
+    auto stage_async = [&](const float *src) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int blk = 3 * wv + k;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + blk * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void *)(tStage + blk * 256), 16, 0, 0);
+        }
+    };
+    auto split_stage = [&]() {                         // tStage (fp32, linear) -> e planes
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = it * 512 + tid;
+            store_split(tE, idx >> 5, idx & 31, ld4(tStage + idx * 4));
+        }
+    };
 
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin;
@@ -118,30 +134,24 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
     f4 gai, gcj[3];
     if (i < tr.end) {
         if (tid < TM_TILE) s_idx[0][tid] = a.E_idx[(size_t)i * TM_KS + tid];
-        const float *src = a.hE + (size_t)i * TM_KS * TM_H;
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int idx = it * 512 + tid;
-            store_split(tE, idx >> 5, idx & 31, ld4(src + (size_t)idx * 4));
-        }
+        stage_async(a.hE + (size_t)i * TM_KS * TM_H);
         __syncthreads();
+        split_stage();
         gai = ld4(a.P + (size_t)i * 256 + ncol);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             const int j = s_idx[0][16 * rb + m];
             gcj[rb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol);
         }
+        __syncthreads();
     }
     for (; i < tr.end; i += tr.step) {
         float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
         const int inext = i + tr.step;
         const bool has_next = inext < tr.end;
-        f4 pre[3];
         int nidx = -1;
         if (has_next) {
-            const float *src = a.hE + (size_t)inext * TM_KS * TM_H;
-#pragma unroll
-            for (int it = 0; it < 3; ++it) pre[it] = ld4(src + (size_t)(it * 512 + tid) * 4);
+            stage_async(a.hE + (size_t)inext * TM_KS * TM_H);
             if (tid < TM_TILE) nidx = a.E_idx[(size_t)inext * TM_KS + tid];
         }
         f4 acc[3][1];
@@ -149,7 +159,10 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
         mma_tile_bf3<4, 1>(tE, w11, acc, lane);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) store_split(tX, 16 * rb + m, c4, gelu4(acc[rb][0]));
+        for (int rb = 0; rb < 3; ++rb) {
+            store_split(tX, 16 * rb + m, c4, gelu4(acc[rb][0]));
+            __builtin_amdgcn_sched_barrier(0);      // one row block at a time: keeps the GELU temporaries out of the weight VGPRs
+        }
         if (has_next && tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx;
         __syncthreads();
 
@@ -161,15 +174,24 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
                 gcj[rb] = ld4(a.P + (size_t)(j < 0 ? inext : j) * 256 + 128 + ncol);
             }
         }
+        {
+            const f4 b12 = ld4(a.b12 + ncol);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
+            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
+        }
         mma_tile_bf3<4, 1>(tX, w12, acc, lane);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) store_split(tY, 16 * rb + m, c4, gelu4(acc[rb][0]));
+        for (int rb = 0; rb < 3; ++rb) {
+            store_split(tY, 16 * rb + m, c4, gelu4(acc[rb][0]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();
 
+        {
+            const f4 b13 = ld4(a.b13 + ncol);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
+            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
+        }
         mma_tile_bf3<4, 1>(tY, w13, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
@@ -179,20 +201,17 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
         }
         __syncthreads();                                                     // tE free, tO + stats complete
 
-        if (has_next) {
+        if (has_next) split_stage();
+        {
+            const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
 #pragma unroll
             for (int it = 0; it < 3; ++it) {
-                const int idx = it * 512 + tid;
-                store_split(tE, idx >> 5, idx & 31, pre[it]);
+                const int row = 6 * wv + 2 * it + (lane >> 5);
+                float mean, rstd;
+                row_stats_finish8b(&s_stat[row][0], mean, rstd);
+                const f4 y = (ld4(tO + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
+                if (s_idx[cur][row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
             }
-        }
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int row = 6 * wv + 2 * it + (lane >> 5);
-            float mean, rstd;
-            row_stats_finish8b(&s_stat[row][0], mean, rstd);
-            const f4 y = (ld4(tO + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
-            if (s_idx[cur][row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
         }
         cur ^= 1;
         __syncthreads();
