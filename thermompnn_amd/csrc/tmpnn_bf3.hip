@@ -246,6 +246,7 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
     __shared__ __attribute__((aligned(16))) char tE[BF3_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) char tA[BF3_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float tS[TM_TILE * TM_H];
+    __shared__ __attribute__((aligned(16))) float tStage[TM_TILE * TM_H];   // next residue's fp32 tile, landed by LDS-DMA
     __shared__ float s_part[3][TM_H];
     __shared__ int s_idx[2][TM_TILE];
     __shared__ float s_ma[2][TM_TILE];
@@ -257,17 +258,29 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
     const f4 bias2 = ld4(a.b2 + ncol);
 
-    const TileRange tr = xcd_tile_range(a.T);
-    int i = tr.begin;
-    int cur = 0;
-    f4 g0, gj[3];                       // node terms of the tile about to be processed (see gather())
-    auto stage_idx = [&](int ii, int buf) {       // neighbour list + attention mask of residue ii -> LDS
+    auto stage_async = [&](const float *src) {        // linear LDS-DMA of one fp32 tile: 24 x 1 KB, three per wavefront
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int blk = 3 * wv + k;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + blk * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void *)(tStage + blk * 256), 16, 0, 0);
+        }
+    };
+    auto split_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = it * 512 + tid;
+            store_split(tE, idx >> 5, idx & 31, ld4(tStage + idx * 4));
+        }
+    };
+    auto stage_idx = [&](int ii, int buf) {           // neighbour list + attention mask of residue ii -> LDS
         if (tid < TM_TILE) {
             const int j = a.E_idx[(size_t)ii * TM_KS + tid];
             s_idx[buf][tid] = j;
             s_ma[buf][tid] = j < 0 ? 0.f : (DEC ? 1.f : a.mask[ii] * a.mask[j]);
         }
     };
+    f4 g0, gj[3];                                      // node terms of the tile about to be processed
     auto gather = [&](int ii, int buf) {
         g0 = ld4(a.P + (size_t)ii * 256 + ncol);
 #pragma unroll
@@ -278,26 +291,24 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
             if (DEC) gj[rb] += ld4(a.seq_table + a.S[j] * TM_H + ncol);
         }
     };
+
+    const TileRange tr = xcd_tile_range(a.T);
+    int i = tr.begin;
+    int cur = 0;
     if (i < tr.end) {
         stage_idx(i, 0);
-        const float *src = a.hE + (size_t)i * TM_KS * TM_H;
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int idx = it * 512 + tid;
-            store_split(tE, idx >> 5, idx & 31, ld4(src + (size_t)idx * 4));
-        }
+        stage_async(a.hE + (size_t)i * TM_KS * TM_H);
         __syncthreads();
+        split_stage();
         gather(i, 0);
+        __syncthreads();
     }
     for (; i < tr.end; i += tr.step) {
         const int inext = i + tr.step;
         const bool has_next = inext < tr.end;
         const float mi = a.mask[i];
-        f4 pre[3];
         if (has_next) {
-            const float *src = a.hE + (size_t)inext * TM_KS * TM_H;
-#pragma unroll
-            for (int it = 0; it < 3; ++it) pre[it] = ld4(src + (size_t)(it * 512 + tid) * 4);
+            stage_async(a.hE + (size_t)inext * TM_KS * TM_H);
             stage_idx(inext, cur ^ 1);
         }
         f4 acc[3][1];
@@ -310,14 +321,10 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
             if (DEC) v = g0 + mi * v;
             store_split(tA, 16 * rb + m, c4, gelu4(v));
         }
-        __syncthreads();                                         // tE consumed; tA, s_idx/s_ma[next] complete
+        __syncthreads();                                         // tE consumed; tA, tStage, s_idx/s_ma[next] complete
 
         if (has_next) {
-#pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int idx = it * 512 + tid;
-                store_split(tE, idx >> 5, idx & 31, pre[it]);
-            }
+            split_stage();
             gather(inext, cur ^ 1);
         }
 #pragma unroll
@@ -330,6 +337,11 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
             if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
             st4(tS + chunk_off(16 * rb + m, c4), v);
         }
+        if (tid == 128) {                                        // neighbour count of this tile (read before s_ma[cur] is recycled)
+            float c = 0.f;
+            for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
+            a.cnt[i] = c;
+        }
         __syncthreads();
         {   // per-node aggregation: column sums over 4 row groups of 12, combined in a fixed order
             const int n = tid & 127, grp = tid >> 7;
@@ -339,14 +351,11 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
             if (grp) s_part[grp - 1][n] = s;
             __syncthreads();
             if (!grp) a.Ssum[(size_t)i * TM_H + n] = ((s + s_part[0][n]) + s_part[1][n]) + s_part[2][n];
-            if (tid == 128) {
-                float c = 0.f;
-                for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
-                a.cnt[i] = c;
-            }
         }
         cur ^= 1;
-        __syncthreads();
+        // no barrier here: the next iteration writes tA only after its own GEMM1 (behind which every wavefront has
+        // passed the barrier above), tS / s_part only after two more barriers, and s_idx/s_ma[cur^1] = the buffers
+        // of the iteration before this one.
     }
 }
 
