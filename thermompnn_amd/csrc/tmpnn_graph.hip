@@ -384,8 +384,9 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
         a.mu[i] = i < 8 ? (float)(2.0 + (20.0 / 15.0) * i) : (float)(22.0 - (20.0 / 15.0) * (15 - i));
     const int64_t cap = tm_num_cus();
     static const int nw = [] { const char *e = getenv("TMPNN_FEAT_WAVES"); return e ? atoi(e) : 8; }();
-    // (a split-precision bf16x3 form of this kernel was measured and dropped: the Gaussian generation + plane splitting
-    //  and its two extra barriers cost as much as the shorter 400->128 GEMM saved; 1.07 vs 1.08 ms)
+    // (two split-precision bf16x3 forms of this kernel — half-width tiles, and one 126 KB single-pass plane tile — were
+    //  measured and dropped: generating + splitting the 19 200 Gaussians into three planes and the extra LDS traffic cost as
+    //  much as the shorter 400->128 GEMM saved: 1.07-1.08 ms vs 1.08 ms)
     tm_prof_begin("featurize", st);
     if (nw == 4) featurize_kernel<4><<<(int)(T < cap ? T : cap), 256, 0, st>>>(a);
     else featurize_kernel<8><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
