@@ -9,14 +9,15 @@
 #include "tmpnn_internal.h"
 
 // ------------------------------------------------------------------------------------------------
-// knn_topk: one wavefront per residue row. The row's adjusted distances live in LDS; selection is
-// K rounds of a wavefront-wide 64-bit (distance bits, index) min with per-lane cached minima.
+// knn_topk: one wavefront per residue row. The row's adjusted distances live in LDS; selection is K rounds of a
+// wavefront-wide 32-bit min over per-lane cached minima (distance bit patterns; a ballot resolves the owner lane, a
+// second min only on exact ties), after which the owner lane retires the element and rescans its stripe.
 //   D = m_i m_j sqrt(|Ca_i - Ca_j|^2 + 1e-6);  D_adj = D + (1 - m_i m_j) max_j D      (:1101-1106)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned long long o = __shfl_xor(v, off);
+        const unsigned o = __shfl_xor(v, off);
         v = o < v ? o : v;
     }
     return v;
@@ -34,7 +35,6 @@ __global__ __launch_bounds__(TM_THREADS) void knn_kernel(const float *__restrict
     extern __shared__ __attribute__((aligned(16))) float knn_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float *d = knn_lds + (size_t)wv * max_len;
-    const unsigned long long KEY_INF = ~0ull;
 
     for (int i = blockIdx.x * 4 + wv; i < T; i += gridDim.x * 4) {
         int lo = 0, hi = N;                      // protein p with offsets[p] <= i < offsets[p+1]
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(TM_THREADS) void knn_kernel(const float *__restrict
         const float mi = mask[i];
 
         float dmax = 0.f;
+#pragma unroll 4
         for (int j = lane; j < L; j += 64) {
             const float *c = X + (size_t)(s + j) * 12 + 3;
             const float dx = c[0] - xi, dy = c[1] - yi, dz = c[2] - zi;
@@ -57,31 +58,39 @@ __global__ __launch_bounds__(TM_THREADS) void knn_kernel(const float *__restrict
             dmax = fmaxf(dmax, D);
         }
         dmax = wave_max_f32(dmax);
-        unsigned long long best = KEY_INF;
+        // per-lane running minimum over its stripe (j = lane, lane + 64, ...): (distance bits, index), lowest index on ties.
+        // Distances are >= +0, so their bit patterns order like the values and a 32-bit unsigned min suffices.
+        unsigned best_d = 0xffffffffu, best_j = 0xffffffffu;
+#pragma unroll 4
         for (int j = lane; j < L; j += 64) {
             const float m2 = mi * mask[s + j];
             const float Da = __fadd_rn(d[j], __fmul_rn(1.0f - m2, dmax));
             d[j] = Da;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(Da) << 32) | (unsigned)j;
-            best = key < best ? key : best;
+            const unsigned bits = __float_as_uint(Da);
+            if (bits < best_d) { best_d = bits; best_j = (unsigned)j; }
         }
         wave_lds_fence();
         for (int t = 0; t < Keff; ++t) {
-            const unsigned long long g = wave_min_u64(best);
-            const int j = (int)(g & 0xffffffffu);
-            if (lane == 0) {
-                E_idx[(size_t)i * TM_KS + t] = s + j;
-                D_nb[(size_t)i * TM_KS + t] = __uint_as_float((unsigned)(g >> 32));
+            const unsigned g = wave_min_u32(best_d);
+            const unsigned long long tied = __ballot(best_d == g);
+            unsigned j;
+            if (__popcll(tied) == 1) {                           // the common case: one lane holds the minimum
+                j = __builtin_amdgcn_readlane(best_j, (int)__ffsll((long long)tied) - 1);
+            } else {                                             // exact tie between lanes: lowest index wins
+                j = wave_min_u32(best_d == g ? best_j : 0xffffffffu);
             }
-            if ((j & 63) == lane) {              // owner lane retires j and rescans its stripe
+            if (lane == 0) {
+                E_idx[(size_t)i * TM_KS + t] = s + (int)j;
+                D_nb[(size_t)i * TM_KS + t] = __uint_as_float(g);
+            }
+            if ((j & 63u) == (unsigned)lane) {                   // owner lane retires j and rescans its stripe
                 d[j] = __uint_as_float(0x7f800000u);
-                best = KEY_INF;
+                best_d = 0xffffffffu;
+                best_j = 0xffffffffu;
+#pragma unroll 2
                 for (int jj = lane; jj < L; jj += 64) {
                     const unsigned bits = __float_as_uint(d[jj]);
-                    if (bits != 0x7f800000u) {
-                        const unsigned long long key = ((unsigned long long)bits << 32) | (unsigned)jj;
-                        best = key < best ? key : best;
-                    }
+                    if (bits != 0x7f800000u && bits < best_d) { best_d = bits; best_j = (unsigned)jj; }
                 }
             }
         }
