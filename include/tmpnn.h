@@ -50,10 +50,12 @@ typedef void *tmpnn_stream_t;                   /* hipStream_t */
 
 int tmpnn_version(void);
 const char *tmpnn_last_error(void);
-/* "bf16x3" (default) or "fp32": how the per-edge 128x128 GEMMs of the message / edge-update kernels run on the matrix
- * cores. bf16x3 = every fp32 operand split exactly into three bf16 values, six partial products per term on
- * v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-class accuracy, ~2.2x the fp32-MFMA GEMM rate); fp32 = exact
- * v_mfma_f32_16x16x4_f32. Selected once per process by the environment variable TMPNN_PRECISION. */
+/* "f16x2" (default), "bf16x3" or "fp32": how the per-edge GEMMs (featurizer, message and edge-update kernels) run on
+ * the matrix cores. f16x2 = every fp32 operand kept as two fp16 values x = h + l*2^-11 (22 significant bits), three
+ * partial products per term on v_mfma_f32_16x16x32_f16 with fp32 accumulation; bf16x3 = exact three-way bf16 split, six
+ * partial products on v_mfma_f32_16x16x32_bf16 (full fp32 range); fp32 = v_mfma_f32_16x16x4_f32. All three are in the
+ * same accuracy class (see thermompnn_amd/csrc/tmpnn_split.h) and pass the same parity tests.
+ * Selected once per process by the environment variable TMPNN_PRECISION. */
 const char *tmpnn_matmul_mode(void);
 
 /* ---- weights ------------------------------------------------------------------------------------
@@ -190,7 +192,8 @@ int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const float *P, f
 int tmpnn_profile_fetch(const char **names, double *total_ms, int64_t *launches, int capacity);
 
 /* GEMM core probe: Y[t] = reps x (X[t] W^T) for T tiles of [48,128] and one [128,128] weight; mode 0 = exact fp32 MFMA,
- * mode 1 = six-term bf16 split MFMA (tmpnn_bf3.h). For accuracy / speed comparisons of the two matrix-core paths. */
+ * mode 1 = six-term bf16x3 split MFMA, mode 2 = three-term f16x2 split MFMA (tmpnn_split.h). For accuracy / speed
+ * comparisons of the matrix-core paths. */
 int tmpnn_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, tmpnn_stream_t stream);
 
 /* Effective shader clock under a saturated fp32-MFMA stream (192 v_mfma_f32_16x16x4_f32 per iteration per wavefront,

@@ -93,14 +93,25 @@ int tm_num_cus() {
     return n;
 }
 
-// Matrix-core path of the per-edge 128x128 GEMMs (message + edge-update kernels): "bf16x3" (default) = six-term split
-// products on the bf16 matrix cores with fp32 accumulation, fp32-class accuracy (tmpnn_bf3.h); "fp32" = exact
-// v_mfma_f32_16x16x4_f32. Both pass the same parity tests; bf16x3 is ~1.23x faster end to end on MI355X.
-bool tm_use_bf3() {
-    static const bool v = [] { const char *e = getenv("TMPNN_PRECISION"); return e == nullptr || strcmp(e, "fp32") != 0; }();
+// Matrix-core path of the per-edge GEMMs (featurizer, message and edge-update kernels), see tmpnn_split.h:
+//   "f16x2" (default) three-term fp16 split products, "bf16x3" six-term bf16 split products (both on the 16-bit matrix
+//   cores with fp32 accumulation, fp32-class accuracy), "fp32" = v_mfma_f32_16x16x4_f32. All pass the same parity tests.
+int tm_matmul_mode() {
+    static const int v = [] {
+        const char *e = getenv("TMPNN_PRECISION");
+        if (e == nullptr || e[0] == 0 || strcmp(e, "f16x2") == 0) return (int)TM_MM_F16X2;
+        if (strcmp(e, "bf16x3") == 0) return (int)TM_MM_BF16X3;
+        if (strcmp(e, "fp32") == 0) return (int)TM_MM_FP32;
+        fprintf(stderr, "tmpnn: unknown TMPNN_PRECISION '%s' (f16x2 | bf16x3 | fp32)\n", e);
+        abort();
+        return (int)TM_MM_F16X2;
+    }();
     return v;
 }
-extern "C" const char *tmpnn_matmul_mode(void) { return tm_use_bf3() ? "bf16x3" : "fp32"; }
+extern "C" const char *tmpnn_matmul_mode(void) {
+    const int m = tm_matmul_mode();
+    return m == TM_MM_F16X2 ? "f16x2" : m == TM_MM_BF16X3 ? "bf16x3" : "fp32";
+}
 
 extern "C" int tmpnn_version(void) { return TMPNN_VERSION; }
 extern "C" const char *tmpnn_last_error(void) { return g_err; }
@@ -407,9 +418,9 @@ extern "C" int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const 
     return launch_enc_edge(w->enc[layer], P, h_E, E_idx, T, (hipStream_t)stream, ablation);
 }
 
-// measurement hook (tools/gemm_probe.py): one [48x128] x [128x128]^T GEMM per tile, mode 0 = fp32 MFMA, 1 = six-term bf16 MFMA
+// measurement hook (tools/gemm_probe.py): one [48x128] x [128x128]^T GEMM per tile, mode 0 = fp32 MFMA, 1 = bf16x3 six-term, 2 = f16x2 three-term
 extern "C" int tmpnn_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, tmpnn_stream_t stream) {
-    REQUIRE(X && W && Y && T > 0 && reps > 0 && (mode == 0 || mode == 1), "gemm_probe: bad argument");
+    REQUIRE(X && W && Y && T > 0 && reps > 0 && mode >= 0 && mode <= 2, "gemm_probe: bad argument");
     return launch_gemm_probe(mode, X, W, Y, T, reps, (hipStream_t)stream);
 }
 

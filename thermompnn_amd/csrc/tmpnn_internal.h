@@ -76,12 +76,14 @@ int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float 
 int launch_prep_tables(tmpnn_weights *w, hipStream_t st);
 
 int launch_clock_probe(int blocks, int iters, unsigned long long *out, float *sink, hipStream_t st);
-// tmpnn_bf3.hip
-int launch_enc_edge_bf3(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
-int launch_msg_bf3(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
-                   const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
-                   int64_t T, float *Ssum, float *cnt, hipStream_t st);
+// tmpnn_split.hip (mode = TM_MM_F16X2 | TM_MM_BF16X3)
+int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
+int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
+                     const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
+                     int64_t T, float *Ssum, float *cnt, hipStream_t st);
 int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, hipStream_t st);
 
 int tm_num_cus();
-bool tm_use_bf3();     // TMPNN_PRECISION=bf16x3 (default) | fp32: matrix-core path of the per-edge GEMMs
+// TMPNN_PRECISION = f16x2 (default) | bf16x3 | fp32: matrix-core path of the per-edge GEMMs (tmpnn_split.h)
+enum { TM_MM_FP32 = 0, TM_MM_BF16X3 = 1, TM_MM_F16X2 = 2 };
+int tm_matmul_mode();

@@ -952,9 +952,8 @@ int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float
     static const int nw = [] { const char *e = getenv("TMPNN_MSG_WAVES"); return e ? atoi(e) : 4; }();
     const int grid = grid_for(T, 2);
     tm_prof_begin(dec ? "dec_msg" : "enc_msg", st);
-    static const bool msg_bf3 = [] { const char *e = getenv("TMPNN_MSG_BF3"); return e == nullptr || e[0] != '0'; }();
-    if (tm_use_bf3() && msg_bf3) {
-        const int rc = launch_msg_bf3(dec, W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, T, Ssum, cnt, st);
+    if (tm_matmul_mode() != TM_MM_FP32) {
+        const int rc = launch_msg_split(tm_matmul_mode(), dec, W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, T, Ssum, cnt, st);
         tm_prof_end(st);
         return rc;
     }
@@ -977,9 +976,10 @@ int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_i
     // selectable for experiments: TMPNN_ENC_EDGE_VARIANT = 1 (4-wavefront), 16 (ping-pong), 64 (2 workgroups per CU),
     // or the ablation codes of tmpnn_ablate_enc_edge (0 there means the 4-wavefront kernel).
     static const int variant = [] { const char *e = getenv("TMPNN_ENC_EDGE_VARIANT"); return e ? atoi(e) : 32; }();
-    if (abl < 0) abl = tm_use_bf3() ? 128 : (variant == 1 ? 0 : variant);
-    if (abl == 128) {      // split-precision bf16 matrix-core form (tmpnn_bf3.hip)
-        const int rc = launch_enc_edge_bf3(e, P, hE, E_idx, T, st);
+    if (abl < 0) abl = tm_matmul_mode() != TM_MM_FP32 ? 128 : (variant == 1 ? 0 : variant);
+    if (abl == 128 || abl == 129) {      // split-precision 16-bit matrix-core forms (tmpnn_split.hip); 129 forces bf16x3
+        const int mode = abl == 129 || tm_matmul_mode() == TM_MM_BF16X3 ? TM_MM_BF16X3 : TM_MM_F16X2;
+        const int rc = launch_enc_edge_split(mode, e, P, hE, E_idx, T, st);
         tm_prof_end(st);
         return rc;
     }

@@ -1,22 +1,26 @@
-// Split-precision (bf16 x 3, six-term) forms of the per-edge kernels. See tmpnn_bf3.h for the arithmetic.
+// Split-precision forms of the per-edge kernels (f16x2 three-term / bf16x3 six-term). See tmpnn_split.h for the arithmetic.
 #include <stdlib.h>
 
-#include "tmpnn_bf3.h"
+#include <type_traits>
+
+#include "tmpnn_split.h"
 #include "tmpnn_internal.h"
 
 // ------------------------------------------------------------------------------------------------
-// GEMM probe (tools/gemm_probe.py): Y[t] = X[t] W^T per 48 x 128 tile, fp32 MFMA vs six-term bf16 MFMA, 8 wavefronts
+// GEMM probe (tools/gemm_probe.py): Y[t] = X[t] W^T per 48 x 128 tile, 8 wavefronts.
+// MODE 0 = fp32 MFMA, 1 = bf16x3 six-term, 2 = f16x2 three-term
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_probe_kernel(const float *__restrict__ X, const float *__restrict__ W,
                                                             float *__restrict__ Y, int T, int reps) {
     __shared__ __attribute__((aligned(16))) float tF[TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) char tP[BF3_TILE_BYTES];
+    using SP = typename std::conditional<MODE == 2, SplitH2, SplitBF3>::type;
+    __shared__ __attribute__((aligned(16))) char tP[3 * SPLIT_PLANE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     float wf[1][32];
-    WFrag3 w3[1][4];
+    WFragS<SP> w3[1][4];
     if (MODE == 0) load_wfrag<8>(W, TM_H, 16 * wv, 0, TM_H, wf[0], lane);
-    else load_wfrag_bf3<4>(W, TM_H, 16 * wv, 0, TM_H, w3[0], lane);
+    else load_wfrag_split<SP, 4>(W, TM_H, 16 * wv, 0, TM_H, w3[0], lane);
     for (int i = blockIdx.x; i < T; i += gridDim.x) {
         const float *src = X + (size_t)i * TM_TILE * TM_H;
 #pragma unroll
@@ -24,7 +28,7 @@ __global__ __launch_bounds__(512, 2) void gemm_probe_kernel(const float *__restr
             const int idx = it * 512 + tid, row = idx >> 5, c = idx & 31;
             const f4 v = ld4(src + (size_t)idx * 4);
             if (MODE == 0) st4(tF + chunk_off(row, c), v);
-            else store_split(tP, row, c, v);
+            else store_split<SP>(tP, row, c, v);
         }
         __syncthreads();
         f4 acc[3][1];
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(512, 2) void gemm_probe_kernel(const float *__restr
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = f4{0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < reps; ++r) {
             if (MODE == 0) mma_tile<8, 1>(tF, wf, acc, lane);
-            else mma_tile_bf3<4, 1>(tP, w3, acc, lane);
+            else mma_tile_split<SP, 4, 1>(tP, w3, acc, lane);
         }
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb)
@@ -45,17 +49,18 @@ int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
     if (mode == 0) gemm_probe_kernel<0><<<grid, 512, 0, st>>>(X, W, Y, (int)T, reps);
-    else gemm_probe_kernel<1><<<grid, 512, 0, st>>>(X, W, Y, (int)T, reps);
+    else if (mode == 1) gemm_probe_kernel<1><<<grid, 512, 0, st>>>(X, W, Y, (int)T, reps);
+    else gemm_probe_kernel<2><<<grid, 512, 0, st>>>(X, W, Y, (int)T, reps);
     return tm_check_launch("gemm_probe");
 }
 
 
 // ------------------------------------------------------------------------------------------------
 // enc_edge, split-precision form (8 wavefronts, 1 workgroup per CU): same pipeline as enc_edge8_kernel
-// (tmpnn_layers.hip) with the three 128x128 GEMMs on the bf16 matrix cores. GEMM inputs live in LDS as plane tiles;
-// the residual re-joins the planes exactly (x = h + m + l); the LayerNorm input is an fp32 tile aliased on the x planes.
-// The next residue's tile is prefetched into registers at the top of the iteration and split into the e planes
-// during the LayerNorm/store phase.
+// (tmpnn_layers.hip) with the three 128x128 GEMMs on the 16-bit matrix cores. GEMM inputs live in LDS as plane tiles;
+// the LayerNorm input is an fp32 tile aliased on the x planes. The next residue's fp32 tile lands in an LDS staging
+// buffer by LDS-DMA under GEMM 1 and is split into the e planes during the LayerNorm/store phase. Residual: bf16x3
+// re-joins the e planes (exact); f16x2 keeps the fp32 tile (two staging buffers, alternating).
 // ------------------------------------------------------------------------------------------------
 struct EdgeArgsB {
     const float *W11e, *W12, *b12, *W13, *b13, *g3, *be3, *P;
@@ -94,25 +99,29 @@ __device__ __forceinline__ void row_stats_finish8b(const float *stat_row, float 
     rstd = 1.0f / sqrtf((m2 + 16.f * dd) * (1.0f / 128.0f) + 1e-5f);
 }
 
-__global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
-    __shared__ __attribute__((aligned(16))) char tE[BF3_TILE_BYTES];
-    __shared__ __attribute__((aligned(16))) char tX[BF3_TILE_BYTES];     // x planes; later the fp32 LayerNorm input
-    __shared__ __attribute__((aligned(16))) char tY[BF3_TILE_BYTES];
-    __shared__ __attribute__((aligned(16))) float tStage[TM_TILE * TM_H]; // next residue's fp32 tile, landed by LDS-DMA
+template <typename SP>
+__global__ __launch_bounds__(512, 2) void enc_edge8_split_kernel(EdgeArgsB a) {
+    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
+    constexpr int NST = SP::EXACT ? 1 : 2;                               // fp32 staging buffers
+    static_assert(TILEB >= TM_TILE * TM_H * 4, "the fp32 LayerNorm tile is aliased on the x planes");
+    __shared__ __attribute__((aligned(16))) char tE[TILEB];
+    __shared__ __attribute__((aligned(16))) char tX[TILEB];              // x planes; later the fp32 LayerNorm input
+    __shared__ __attribute__((aligned(16))) char tY[TILEB];
+    __shared__ __attribute__((aligned(16))) float tStageB[NST][TM_TILE * TM_H]; // fp32 tiles landed by LDS-DMA
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
     __shared__ int s_idx[2][TM_TILE];
     float *tO = reinterpret_cast<float *>(tX);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
-    WFrag3 w11[1][4], w12[1][4], w13[1][4];
-    load_wfrag_bf3<4>(a.W11e, 384, 16 * wv, 0, TM_H, w11[0], lane);
-    load_wfrag_bf3<4>(a.W12, TM_H, 16 * wv, 0, TM_H, w12[0], lane);
-    load_wfrag_bf3<4>(a.W13, TM_H, 16 * wv, 0, TM_H, w13[0], lane);
+    WFragS<SP> w11[1][4], w12[1][4], w13[1][4];
+    load_wfrag_split<SP, 4>(a.W11e, 384, 16 * wv, 0, TM_H, w11[0], lane);
+    load_wfrag_split<SP, 4>(a.W12, TM_H, 16 * wv, 0, TM_H, w12[0], lane);
+    load_wfrag_split<SP, 4>(a.W13, TM_H, 16 * wv, 0, TM_H, w13[0], lane);
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
     const int c32 = lane & 31;
 
     // linear (unswizzled) LDS-DMA of one fp32 tile: 24 wave-instructions of 1 KB, three per wavefront
-    auto stage_async = [&](const float *src) {
+    auto stage_async = [&](const float *src, float *tStage) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int blk = 3 * wv + k;
@@ -120,23 +129,23 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
                                              (__attribute__((address_space(3))) void *)(tStage + blk * 256), 16, 0, 0);
         }
     };
-    auto split_stage = [&]() {                         // tStage (fp32, linear) -> e planes
+    auto split_stage = [&](const float *tStage) {      // tStage (fp32, linear) -> e planes
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int idx = it * 512 + tid;
-            store_split(tE, idx >> 5, idx & 31, ld4(tStage + idx * 4));
+            store_split<SP>(tE, idx >> 5, idx & 31, ld4(tStage + idx * 4));
         }
     };
 
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin;
-    int cur = 0;
+    int cur = 0, sb = 0;                               // s_idx buffer / staging buffer of the current tile
     f4 gai, gcj[3];
     if (i < tr.end) {
         if (tid < TM_TILE) s_idx[0][tid] = a.E_idx[(size_t)i * TM_KS + tid];
-        stage_async(a.hE + (size_t)i * TM_KS * TM_H);
+        stage_async(a.hE + (size_t)i * TM_KS * TM_H, tStageB[0]);
         __syncthreads();
-        split_stage();
+        split_stage(tStageB[0]);
         gai = ld4(a.P + (size_t)i * 256 + ncol);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
@@ -150,17 +159,18 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
         const int inext = i + tr.step;
         const bool has_next = inext < tr.end;
         int nidx = -1;
+        const int sn = NST == 2 ? sb ^ 1 : 0;
         if (has_next) {
-            stage_async(a.hE + (size_t)inext * TM_KS * TM_H);
+            stage_async(a.hE + (size_t)inext * TM_KS * TM_H, tStageB[sn]);
             if (tid < TM_TILE) nidx = a.E_idx[(size_t)inext * TM_KS + tid];
         }
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
-        mma_tile_bf3<4, 1>(tE, w11, acc, lane);
+        mma_tile_split<SP, 4, 1>(tE, w11, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
-            store_split(tX, 16 * rb + m, c4, gelu4(acc[rb][0]));
+            store_split<SP>(tX, 16 * rb + m, c4, gelu4(acc[rb][0]));
             __builtin_amdgcn_sched_barrier(0);      // one row block at a time: keeps the GELU temporaries out of the weight VGPRs
         }
         if (has_next && tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx;
@@ -179,10 +189,10 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
         }
-        mma_tile_bf3<4, 1>(tX, w12, acc, lane);
+        mma_tile_split<SP, 4, 1>(tX, w12, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
-            store_split(tY, 16 * rb + m, c4, gelu4(acc[rb][0]));
+            store_split<SP>(tY, 16 * rb + m, c4, gelu4(acc[rb][0]));
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -192,16 +202,19 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
         }
-        mma_tile_bf3<4, 1>(tY, w13, acc, lane);
+        mma_tile_split<SP, 4, 1>(tY, w13, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
-            const f4 v = load_joined(tE, 16 * rb + m, c4) + acc[rb][0];     // residual (exact re-join of e)
+            const int row = 16 * rb + m;
+            const f4 e = SP::EXACT ? load_joined<SP>(tE, row, c4)            // residual: exact re-join of the e planes
+                                   : ld4(tStageB[sb] + row * TM_H + 4 * c4); //           or the fp32 tile itself
+            const f4 v = e + acc[rb][0];
             st4(tO + chunk_off(16 * rb + m, c4), v);
             row_stats_partial1b(v, &s_stat[16 * rb + m][2 * wv], q);
         }
         __syncthreads();                                                     // tE free, tO + stats complete
 
-        if (has_next) split_stage();
+        if (has_next) split_stage(tStageB[sn]);
         {
             const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
 #pragma unroll
@@ -214,15 +227,18 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_bf3_kernel(EdgeArgsB a) {
             }
         }
         cur ^= 1;
+        sb = sn;
         __syncthreads();
     }
 }
 
-int launch_enc_edge_bf3(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
+int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
     EdgeArgsB a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
     const int64_t cap = tm_num_cus();
-    enc_edge8_bf3_kernel<<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
-    return tm_check_launch("enc_edge_bf3");
+    const int grid = (int)(T < cap ? T : cap);
+    if (mode == TM_MM_BF16X3) enc_edge8_split_kernel<SplitBF3><<<grid, 512, 0, st>>>(a);
+    else enc_edge8_split_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
+    return tm_check_launch("enc_edge_split");
 }
 
 
@@ -241,10 +257,11 @@ struct MsgArgsB {
     int T;
 };
 
-template <bool DEC>
-__global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
-    __shared__ __attribute__((aligned(16))) char tE[BF3_TILE_BYTES];
-    __shared__ __attribute__((aligned(16))) char tA[BF3_TILE_BYTES];
+template <typename SP, bool DEC>
+__global__ __launch_bounds__(512, 2) void msg8_split_kernel(MsgArgsB a) {
+    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
+    __shared__ __attribute__((aligned(16))) char tE[TILEB];
+    __shared__ __attribute__((aligned(16))) char tA[TILEB];
     __shared__ __attribute__((aligned(16))) float tS[TM_TILE * TM_H];
     __shared__ __attribute__((aligned(16))) float tStage[TM_TILE * TM_H];   // next residue's fp32 tile, landed by LDS-DMA
     __shared__ float s_part[3][TM_H];
@@ -252,9 +269,9 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
     __shared__ float s_ma[2][TM_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
-    WFrag3 w1[1][4], w2[1][4];
-    load_wfrag_bf3<4>(a.W1e, a.ld1, 16 * wv, 0, TM_H, w1[0], lane);
-    load_wfrag_bf3<4>(a.W2, TM_H, 16 * wv, 0, TM_H, w2[0], lane);
+    WFragS<SP> w1[1][4], w2[1][4];
+    load_wfrag_split<SP, 4>(a.W1e, a.ld1, 16 * wv, 0, TM_H, w1[0], lane);
+    load_wfrag_split<SP, 4>(a.W2, TM_H, 16 * wv, 0, TM_H, w2[0], lane);
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
     const f4 bias2 = ld4(a.b2 + ncol);
 
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int idx = it * 512 + tid;
-            store_split(tE, idx >> 5, idx & 31, ld4(tStage + idx * 4));
+            store_split<SP>(tE, idx >> 5, idx & 31, ld4(tStage + idx * 4));
         }
     };
     auto stage_idx = [&](int ii, int buf) {           // neighbour list + attention mask of residue ii -> LDS
@@ -314,12 +331,12 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
-        mma_tile_bf3<4, 1>(tE, w1, acc, lane);
+        mma_tile_split<SP, 4, 1>(tE, w1, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             f4 v = acc[rb][0];
             if (DEC) v = g0 + mi * v;
-            store_split(tA, 16 * rb + m, c4, gelu4(v));
+            store_split<SP>(tA, 16 * rb + m, c4, gelu4(v));
         }
         __syncthreads();                                         // tE consumed; tA, tStage, s_idx/s_ma[next] complete
 
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
         }
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = bias2;
-        mma_tile_bf3<4, 1>(tA, w2, acc, lane);
+        mma_tile_split<SP, 4, 1>(tA, w2, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             const float ma = s_ma[cur][16 * rb + m];
@@ -359,13 +376,18 @@ __global__ __launch_bounds__(512, 2) void msg8_bf3_kernel(MsgArgsB a) {
     }
 }
 
-int launch_msg_bf3(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
+int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                    const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
                    int64_t T, float *Ssum, float *cnt, hipStream_t st) {
     MsgArgsB a{W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, Ssum, cnt, (int)T};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
-    if (dec) msg8_bf3_kernel<true><<<grid, 512, 0, st>>>(a);
-    else msg8_bf3_kernel<false><<<grid, 512, 0, st>>>(a);
-    return tm_check_launch(dec ? "dec_msg_bf3" : "enc_msg_bf3");
+    if (mode == TM_MM_BF16X3) {
+        if (dec) msg8_split_kernel<SplitBF3, true><<<grid, 512, 0, st>>>(a);
+        else msg8_split_kernel<SplitBF3, false><<<grid, 512, 0, st>>>(a);
+    } else {
+        if (dec) msg8_split_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
+        else msg8_split_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
+    }
+    return tm_check_launch(dec ? "dec_msg_split" : "enc_msg_split");
 }
