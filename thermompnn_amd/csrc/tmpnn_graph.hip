@@ -7,6 +7,7 @@
 
 #include "tmpnn_common.h"
 #include "tmpnn_internal.h"
+#include "tmpnn_split.h"
 
 // ------------------------------------------------------------------------------------------------
 // knn_topk: one wavefront per residue row. The row's adjusted distances live in LDS; selection is K rounds of a
@@ -266,6 +267,132 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 1)) void featurize_kernel(F
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-precision featurizer (default, f16x2): same pipeline, both GEMMs on the 16-bit matrix cores (tmpnn_split.h).
+// The Gaussians are split into planes as they are generated (they never exist as an fp32 tile); the RBF planes are
+// plain row-major with a 848-byte pitch (416 values + 16 B; 212 dwords = 20 banks mod 64, so the 16-row B-fragment
+// reads are conflict-free without a swizzle). Columns 400..415 are zero K-padding. LayerNorm statistics are taken in the
+// GEMM-1 epilogue (values stay in registers), its output goes straight into the GEMM-2 input planes, which — like the
+// fp32 output tile — are aliased on the dead RBF planes.
+// ------------------------------------------------------------------------------------------------
+#define RBFP_ROWB 848
+template <typename SP>
+__global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
+    constexpr int PLB = TM_TILE * RBFP_ROWB;                 // bytes per RBF plane
+    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
+    static_assert(SP::NP * PLB >= TILEB + TM_TILE * TM_H * 4, "GEMM-2 planes + output tile are aliased on the RBF planes");
+    __shared__ __attribute__((aligned(16))) char rbf[SP::NP * PLB];
+    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
+    __shared__ float s_atoms[TM_TILE][16];
+    __shared__ float s_self[16];
+    __shared__ float s_dist[TM_TILE][28];
+    __shared__ int s_idx[TM_TILE];
+    __shared__ int s_dpos[TM_TILE];
+    char *tAp = rbf;
+    float *tB = reinterpret_cast<float *>(rbf + TILEB);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int c32 = lane & 31;
+    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
+
+    WFragS<SP> wedge[1][13], we[1][4];
+    load_wfrag_split<SP, 13>(a.edge_w, 416, 16 * wv, 16, 400, wedge[0], lane);
+    load_wfrag_split<SP, 4>(a.We_w, TM_H, 16 * wv, 0, TM_H, we[0], lane);
+    const f4 be = ld4(a.We_b + ncol);
+    const f4 g4 = ld4(a.ln_w + ncol), b4 = ld4(a.ln_b + ncol);
+    f4 mu4;                                                   // this thread's 4 Gaussian centres: (tid & 3) is fixed
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mu4[r] = a.mu[(tid & 3) * 4 + r];
+
+    const TileRange tr = xcd_tile_range(a.T);
+    for (int i = tr.begin; i < tr.end; i += tr.step) {
+        if (tid < TM_TILE) {
+            const int j = a.E_idx[(size_t)i * TM_KS + tid];
+            s_idx[tid] = j;
+            const int jj = j < 0 ? i : j;
+            float at[15];
+            atoms5(a.X + (size_t)jj * 12, at);
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s_atoms[tid][k] = at[k];
+            // PositionalEncodings index (:903-905, :1170-1175)
+            const int off = a.ridx[i] - a.ridx[jj];
+            const int same = a.cenc[i] == a.cenc[jj];
+            s_dpos[tid] = same ? min(max(off + 32, 0), 64) : 65;
+        } else if (tid == 64) {
+            float at[15];
+            atoms5(a.X + (size_t)i * 12, at);
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s_self[k] = at[k];
+        }
+        __syncthreads();                                       // also: every wavefront is done with the previous tile's tB
+        for (int e = tid; e < TM_TILE * 25; e += 512) {
+            const int mm = e / 25, p = e - mm * 25;
+            float D;
+            if (p == 0) {
+                D = a.D_nb[(size_t)i * TM_KS + mm];            // masked Ca-Ca distance from _dist (:1142)
+            } else {
+                const float *A = s_self + 3 * c_pair_a[p];
+                const float *B = s_atoms[mm] + 3 * c_pair_b[p];
+                const float dx = A[0] - B[0], dy = A[1] - B[1], dz = A[2] - B[2];
+                D = sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);  // _get_rbf (:1122)
+            }
+            s_dist[mm][p] = D;
+        }
+        if (tid < TM_TILE * 2 * SP::NP) {                       // zero the K padding (columns 400..415) of every plane row
+            const int p = tid / (TM_TILE * 2), rem = tid - p * (TM_TILE * 2);
+            *reinterpret_cast<u4 *>(rbf + p * PLB + (rem >> 1) * RBFP_ROWB + 800 + 16 * (rem & 1)) = u4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();
+        for (int e = tid; e < TM_TILE * 100; e += 512) {        // 16 Gaussians per pair, 4 per thread (:1111-1119)
+            const int mm = e / 100, c = e - mm * 100;
+            const float D = s_dist[mm][c >> 2];
+            f4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = (D - mu4[r]) * 0.8f;            // / sigma, sigma = 1.25
+                v[r] = __expf(-(t * t));
+            }
+            unsigned lo2[SP::NP], hi2[SP::NP];
+            SP::split2(f2{v.x, v.y}, lo2);
+            SP::split2(f2{v.z, v.w}, hi2);
+#pragma unroll
+            for (int p = 0; p < SP::NP; ++p)
+                *reinterpret_cast<u2 *>(rbf + p * PLB + mm * RBFP_ROWB + c * 8) = u2{lo2[p], hi2[p]};
+        }
+        __syncthreads();
+
+        f4 acc[3][1];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_dpos[16 * rb + m] * TM_H + ncol);
+        mma_tile_split<SP, 13, 1, 3, TM_TILE, RBFP_ROWB, 13, 0, false>(rbf, wedge, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) row_stats_partial1b(acc[rb][0], &s_stat[16 * rb + m][2 * wv], q);
+        __syncthreads();                                       // RBF planes dead, statistics complete
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {                        // norm_edges (:1179)
+            const int row = 16 * rb + m;
+            float mean, rstd;
+            row_stats_finish8b(&s_stat[row][0], mean, rstd);
+            const f4 y = (acc[rb][0] - mean) * rstd * g4 + b4;
+            store_split<SP>(tAp, row, c4, y);
+            if (a.E_opt) st4(a.E_opt + ((size_t)i * TM_KS + row) * TM_H + ncol, s_idx[row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = be;
+        mma_tile_split<SP, 4, 1>(tAp, we, acc, lane);           // W_e (:1229)
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) st4(tB + chunk_off(16 * rb + m, c4), acc[rb][0]);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int row = 6 * wv + 2 * it + (lane >> 5);
+            const f4 y = s_idx[row] >= 0 ? ld4(tB + chunk_off(row, c32)) : f4{0.f, 0.f, 0.f, 0.f};
+            st4(a.hE + ((size_t)i * TM_KS + row) * TM_H + 4 * c32, y);
+        }
+        __syncthreads();                                       // s_idx / tB are recycled by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // gathers
 // ------------------------------------------------------------------------------------------------
 // out[r, :] = nodes[base(r) + idx[r], :] with C % 4 == 0; one 16-byte chunk per thread-iteration.
@@ -397,6 +524,12 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
     //  measured and dropped: generating + splitting the 19 200 Gaussians into three planes and the extra LDS traffic cost as
     //  much as the shorter 400->128 GEMM saved: 1.07-1.08 ms vs 1.08 ms)
     tm_prof_begin("featurize", st);
+    static const bool split_ok = [] { const char *e = getenv("TMPNN_FEAT_SPLIT"); return e == nullptr || e[0] != '0'; }();
+    if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
+        featurize_split_kernel<SplitH2><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
+        tm_prof_end(st);
+        return tm_check_launch("edge_featurize");
+    }
     if (nw == 4) featurize_kernel<4><<<(int)(T < cap ? T : cap), 256, 0, st>>>(a);
     else featurize_kernel<8><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
     tm_prof_end(st);

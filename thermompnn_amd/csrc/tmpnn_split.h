@@ -109,9 +109,10 @@ __device__ __forceinline__ int plane_off4(int p, int row, int c4) {
     return p * (ROWS * ROWB) + row * ROWB + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3));
 }
 // byte offset of the 16-byte chunk c16 (columns [8*c16, 8*c16+8)) of row `row`, plane p
-template <int ROWS = TM_TILE, int ROWB = 256>
+// (SWZ = false: plain row-major planes whose row pitch ROWB is conflict-free by itself, e.g. 848 B = 20 banks mod 64)
+template <int ROWS = TM_TILE, int ROWB = 256, bool SWZ = true>
 __device__ __forceinline__ int plane_off8(int p, int row, int c16) {
-    return p * (ROWS * ROWB) + row * ROWB + ((c16 ^ (row & 15)) << 4);
+    return p * (ROWS * ROWB) + row * ROWB + ((SWZ ? (c16 ^ (row & 15)) : c16) << 4);
 }
 
 // write four consecutive fp32 columns of one row into the planes (one 8-byte packet per plane)
@@ -167,7 +168,8 @@ __device__ __forceinline__ void load_wfrag_split(const float *__restrict__ W, in
 // acc[rb][cb] += W_cb . tile^T over K = 32*NK32. The low-order terms go through a second accumulator that is folded
 // in at the end, so they are not swamped while the leading term is still growing. The weight fragments used are
 // w[cb][C0 .. C0+NK32) (a K sub-range of a wider weight); the tile starts at its column 0.
-template <typename SP, int NK32, int NCB, int NRB = 3, int ROWS = TM_TILE, int ROWB = 256, int NKTOT = NK32, int C0 = 0>
+template <typename SP, int NK32, int NCB, int NRB = 3, int ROWS = TM_TILE, int ROWB = 256, int NKTOT = NK32, int C0 = 0,
+          bool SWZ = true>
 __device__ __forceinline__ void mma_tile_split(const char *tile, const WFragS<SP> (&w)[NCB][NKTOT], f4 (&acc)[NRB][NCB], int lane) {
     const int m = lane & 15, q = lane >> 4;
     f4 lo[NRB][NCB];
@@ -182,7 +184,7 @@ __device__ __forceinline__ void mma_tile_split(const char *tile, const WFragS<SP
             u4 x[SP::NP];                               // one row block at a time: few B-fragment VGPRs in flight
 #pragma unroll
             for (int p = 0; p < SP::NP; ++p)
-                x[p] = *reinterpret_cast<const u4 *>(tile + plane_off8<ROWS, ROWB>(p, 16 * rb + m, 4 * c + q));
+                x[p] = *reinterpret_cast<const u4 *>(tile + plane_off8<ROWS, ROWB, SWZ>(p, 16 * rb + m, 4 * c + q));
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) SP::mma(w[cb][C0 + c].p, x, acc[rb][cb], lo[rb][cb]);
         }
@@ -191,4 +193,38 @@ __device__ __forceinline__ void mma_tile_split(const char *tile, const WFragS<SP
     for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = SP::fold(acc[rb][cb], lo[rb][cb]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm statistics fused into a GEMM epilogue (8 wavefronts x 16 columns): each wavefront reduces its 16 columns
+// of a row to (mean, M2) over the 4 lane quarters (Chan merge), the 8 partials per row meet in LDS [row][16].
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void row_stats_partial1b(const f4 v, float *stat_slot, int q) {
+    float mean = (v.x + v.y + v.z + v.w) * 0.25f;
+    const f4 d = v - mean;
+    float m2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    float n = 4.f;
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float mo = __shfl_xor(mean, off), m2o = __shfl_xor(m2, off);
+        const float delta = mo - mean;
+        mean = 0.5f * (mean + mo);
+        m2 = m2 + m2o + delta * delta * (0.5f * n);
+        n *= 2.f;
+    }
+    if (q == 0) { stat_slot[0] = mean; stat_slot[1] = m2; }
+}
+__device__ __forceinline__ void row_stats_finish8b(const float *stat_row, float &mean, float &rstd) {
+    f4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = ld4(stat_row + 4 * k);
+    mean = 0.125f * (p[0].x + p[0].z + p[1].x + p[1].z + p[2].x + p[2].z + p[3].x + p[3].z);
+    float m2 = 0.f, dd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float d0 = p[k].x - mean, d1 = p[k].z - mean;
+        m2 += p[k].y + p[k].w;
+        dd += d0 * d0 + d1 * d1;
+    }
+    rstd = 1.0f / sqrtf((m2 + 16.f * dd) * (1.0f / 128.0f) + 1e-5f);
 }

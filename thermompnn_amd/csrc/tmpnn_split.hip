@@ -69,36 +69,6 @@ struct EdgeArgsB {
     int T;
 };
 
-__device__ __forceinline__ void row_stats_partial1b(const f4 v, float *stat_slot, int q) {
-    float mean = (v.x + v.y + v.z + v.w) * 0.25f;
-    const f4 d = v - mean;
-    float m2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
-    float n = 4.f;
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-        const float mo = __shfl_xor(mean, off), m2o = __shfl_xor(m2, off);
-        const float delta = mo - mean;
-        mean = 0.5f * (mean + mo);
-        m2 = m2 + m2o + delta * delta * (0.5f * n);
-        n *= 2.f;
-    }
-    if (q == 0) { stat_slot[0] = mean; stat_slot[1] = m2; }
-}
-__device__ __forceinline__ void row_stats_finish8b(const float *stat_row, float &mean, float &rstd) {
-    f4 p[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) p[k] = ld4(stat_row + 4 * k);
-    mean = 0.125f * (p[0].x + p[0].z + p[1].x + p[1].z + p[2].x + p[2].z + p[3].x + p[3].z);
-    float m2 = 0.f, dd = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float d0 = p[k].x - mean, d1 = p[k].z - mean;
-        m2 += p[k].y + p[k].w;
-        dd += d0 * d0 + d1 * d1;
-    }
-    rstd = 1.0f / sqrtf((m2 + 16.f * dd) * (1.0f / 128.0f) + 1e-5f);
-}
-
 template <typename SP>
 __global__ __launch_bounds__(512, 2) void enc_edge8_split_kernel(EdgeArgsB a) {
     constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
