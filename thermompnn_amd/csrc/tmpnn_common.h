@@ -93,7 +93,30 @@ __device__ __forceinline__ float gelu1(float x) {
     const float h = __builtin_amdgcn_exp2f(fmaf(q, t, -1.0f));
     return x * (0.5f + copysignf(0.5f - h, x));
 }
-__device__ __forceinline__ f4 gelu4(f4 v) { return f4{gelu1(v.x), gelu1(v.y), gelu1(v.z), gelu1(v.w)}; }
+// Two values at a time: the Horner chain, the scalings and the final products run as packed fp32 ops
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes-worth of fp32 per issue slot) — same arithmetic as gelu1.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 gelu2(f2 x) {
+    f2 t = f2{fabsf(x.x), fabsf(x.y)} * 0.70710678118654752440f;
+    t = f2{fminf(t.x, 4.0f), fminf(t.y, 4.0f)};
+    f2 q = f2{2.814671218e-06f, 2.814671218e-06f};
+    q = __builtin_elementwise_fma(q, t, f2{-5.093904975e-05f, -5.093904975e-05f});
+    q = __builtin_elementwise_fma(q, t, f2{3.626021436e-04f, 3.626021436e-04f});
+    q = __builtin_elementwise_fma(q, t, f2{-1.058569948e-03f, -1.058569948e-03f});
+    q = __builtin_elementwise_fma(q, t, f2{-1.620148622e-03f, -1.620148622e-03f});
+    q = __builtin_elementwise_fma(q, t, f2{2.903427724e-02f, 2.903427724e-02f});
+    q = __builtin_elementwise_fma(q, t, f2{-1.488050018e-01f, -1.488050018e-01f});
+    q = __builtin_elementwise_fma(q, t, f2{-9.183712091e-01f, -9.183712091e-01f});
+    q = __builtin_elementwise_fma(q, t, f2{-1.627908858e+00f, -1.627908858e+00f});
+    const f2 e = __builtin_elementwise_fma(q, t, f2{-1.0f, -1.0f});
+    const f2 d = 0.5f - f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    const f2 c = f2{copysignf(d.x, x.x), copysignf(d.y, x.y)};
+    return x * (0.5f + c);
+}
+__device__ __forceinline__ f4 gelu4(f4 v) {
+    const f2 a = gelu2(f2{v.x, v.y}), b = gelu2(f2{v.z, v.w});
+    return f4{a.x, a.y, b.x, b.y};
+}
 
 // Weight fragment for one 16-column block: wr[4*kk+s] = W[(n0 + lane&15) * ld + k0 + 16*kk + 4*(lane>>4) + s].
 // Rows >= n_rows (ragged last block, e.g. 21 logits) read as zero.

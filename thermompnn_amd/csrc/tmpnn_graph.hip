@@ -279,16 +279,16 @@ template <typename SP>
 __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
     constexpr int PLB = TM_TILE * RBFP_ROWB;                 // bytes per RBF plane
     constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
-    static_assert(SP::NP * PLB >= TILEB + TM_TILE * TM_H * 4, "GEMM-2 planes + output tile are aliased on the RBF planes");
+    static_assert(SP::NP * PLB >= TILEB, "the GEMM-2 planes are aliased on the RBF planes");
     __shared__ __attribute__((aligned(16))) char rbf[SP::NP * PLB];
+    __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];   // fp32 output tile
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
     __shared__ float s_atoms[TM_TILE][16];
     __shared__ float s_self[16];
     __shared__ float s_dist[TM_TILE][28];
-    __shared__ int s_idx[TM_TILE];
-    __shared__ int s_dpos[TM_TILE];
+    __shared__ int s_idx[2][TM_TILE];
+    __shared__ int s_dpos[2][TM_TILE];
     char *tAp = rbf;
-    float *tB = reinterpret_cast<float *>(rbf + TILEB);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31;
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
@@ -302,32 +302,43 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) mu4[r] = a.mu[(tid & 3) * 4 + r];
 
-    const TileRange tr = xcd_tile_range(a.T);
-    for (int i = tr.begin; i < tr.end; i += tr.step) {
+    // Per-tile inputs (neighbour list, 5 atoms of every neighbour, positional index, Ca-Ca distance) are fetched into
+    // registers by 49 threads one tile ahead — the dependent global loads (E_idx -> X[j]) fly under GEMM 1.
+    float g_at[15];
+    float g_d0 = 0.f;
+    int g_idx = -1, g_dpos = 0;
+    auto fetch = [&](int ii) {
         if (tid < TM_TILE) {
-            const int j = a.E_idx[(size_t)i * TM_KS + tid];
-            s_idx[tid] = j;
-            const int jj = j < 0 ? i : j;
-            float at[15];
-            atoms5(a.X + (size_t)jj * 12, at);
-#pragma unroll
-            for (int k = 0; k < 15; ++k) s_atoms[tid][k] = at[k];
-            // PositionalEncodings index (:903-905, :1170-1175)
-            const int off = a.ridx[i] - a.ridx[jj];
-            const int same = a.cenc[i] == a.cenc[jj];
-            s_dpos[tid] = same ? min(max(off + 32, 0), 64) : 65;
+            const int j = a.E_idx[(size_t)ii * TM_KS + tid];
+            g_idx = j;
+            const int jj = j < 0 ? ii : j;
+            atoms5(a.X + (size_t)jj * 12, g_at);
+            const int off = a.ridx[ii] - a.ridx[jj];              // PositionalEncodings index (:903-905, :1170-1175)
+            const int same = a.cenc[ii] == a.cenc[jj];
+            g_dpos = same ? min(max(off + 32, 0), 64) : 65;
+            g_d0 = a.D_nb[(size_t)ii * TM_KS + tid];              // masked Ca-Ca distance from _dist (:1142)
         } else if (tid == 64) {
-            float at[15];
-            atoms5(a.X + (size_t)i * 12, at);
-#pragma unroll
-            for (int k = 0; k < 15; ++k) s_self[k] = at[k];
+            atoms5(a.X + (size_t)ii * 12, g_at);
         }
-        __syncthreads();                                       // also: every wavefront is done with the previous tile's tB
+    };
+    auto publish = [&](int buf) {
+        if (tid < TM_TILE) {
+            s_idx[buf][tid] = g_idx;
+            s_dpos[buf][tid] = g_dpos;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s_atoms[tid][k] = g_at[k];
+            s_atoms[tid][15] = g_d0;
+        } else if (tid == 64) {
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s_self[k] = g_at[k];
+        }
+    };
+    auto distances = [&]() {                                    // 25 atom-pair distances of the 48 neighbours
         for (int e = tid; e < TM_TILE * 25; e += 512) {
             const int mm = e / 25, p = e - mm * 25;
             float D;
             if (p == 0) {
-                D = a.D_nb[(size_t)i * TM_KS + mm];            // masked Ca-Ca distance from _dist (:1142)
+                D = s_atoms[mm][15];
             } else {
                 const float *A = s_self + 3 * c_pair_a[p];
                 const float *B = s_atoms[mm] + 3 * c_pair_b[p];
@@ -336,11 +347,24 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
             }
             s_dist[mm][p] = D;
         }
+    };
+
+    const TileRange tr = xcd_tile_range(a.T);
+    int i = tr.begin, cur = 0;
+    if (i < tr.end) {
+        fetch(i);
+        publish(0);
+        __syncthreads();
+        distances();
+        __syncthreads();
+    }
+    for (; i < tr.end; i += tr.step) {
+        const int inext = i + tr.step;
+        const bool has_next = inext < tr.end;
         if (tid < TM_TILE * 2 * SP::NP) {                       // zero the K padding (columns 400..415) of every plane row
             const int p = tid / (TM_TILE * 2), rem = tid - p * (TM_TILE * 2);
             *reinterpret_cast<u4 *>(rbf + p * PLB + (rem >> 1) * RBFP_ROWB + 800 + 16 * (rem & 1)) = u4{0u, 0u, 0u, 0u};
         }
-        __syncthreads();
         for (int e = tid; e < TM_TILE * 100; e += 512) {        // 16 Gaussians per pair, 4 per thread (:1111-1119)
             const int mm = e / 100, c = e - mm * 100;
             const float D = s_dist[mm][c >> 2];
@@ -357,15 +381,17 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
             for (int p = 0; p < SP::NP; ++p)
                 *reinterpret_cast<u2 *>(rbf + p * PLB + mm * RBFP_ROWB + c * 8) = u2{lo2[p], hi2[p]};
         }
-        __syncthreads();
+        __syncthreads();                                       // RBF planes complete; s_dist / s_atoms consumed
 
+        if (has_next) fetch(inext);
         f4 acc[3][1];
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_dpos[16 * rb + m] * TM_H + ncol);
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_dpos[cur][16 * rb + m] * TM_H + ncol);
         mma_tile_split<SP, 13, 1, 3, TM_TILE, RBFP_ROWB, 13, 0, false>(rbf, wedge, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) row_stats_partial1b(acc[rb][0], &s_stat[16 * rb + m][2 * wv], q);
-        __syncthreads();                                       // RBF planes dead, statistics complete
+        if (has_next) publish(cur ^ 1);
+        __syncthreads();                                       // RBF planes dead, statistics + next tile's atoms complete
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {                        // norm_edges (:1179)
             const int row = 16 * rb + m;
@@ -373,22 +399,24 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
             row_stats_finish8b(&s_stat[row][0], mean, rstd);
             const f4 y = (acc[rb][0] - mean) * rstd * g4 + b4;
             store_split<SP>(tAp, row, c4, y);
-            if (a.E_opt) st4(a.E_opt + ((size_t)i * TM_KS + row) * TM_H + ncol, s_idx[row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
+            if (a.E_opt) st4(a.E_opt + ((size_t)i * TM_KS + row) * TM_H + ncol, s_idx[cur][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
         }
+        if (has_next) distances();
         __syncthreads();
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = be;
         mma_tile_split<SP, 4, 1>(tAp, we, acc, lane);           // W_e (:1229)
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) st4(tB + chunk_off(16 * rb + m, c4), acc[rb][0]);
-        __syncthreads();
+        __syncthreads();                                       // tAp consumed (the next Gaussians overwrite it), tB complete
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int row = 6 * wv + 2 * it + (lane >> 5);
-            const f4 y = s_idx[row] >= 0 ? ld4(tB + chunk_off(row, c32)) : f4{0.f, 0.f, 0.f, 0.f};
+            const f4 y = s_idx[cur][row] >= 0 ? ld4(tB + chunk_off(row, c32)) : f4{0.f, 0.f, 0.f, 0.f};
             st4(a.hE + ((size_t)i * TM_KS + row) * TM_H + 4 * c32, y);
         }
-        __syncthreads();                                       // s_idx / tB are recycled by the next tile
+        cur ^= 1;
+        // no barrier: tB is rewritten only after three more barriers, s_idx[cur^1] after one
     }
 }
 

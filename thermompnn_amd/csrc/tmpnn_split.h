@@ -26,7 +26,6 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
@@ -226,5 +225,5 @@ __device__ __forceinline__ void row_stats_finish8b(const float *stat_row, float 
         m2 += p[k].y + p[k].w;
         dd += d0 * d0 + d1 * d1;
     }
-    rstd = 1.0f / sqrtf((m2 + 16.f * dd) * (1.0f / 128.0f) + 1e-5f);
+    rstd = __builtin_amdgcn_rsqf((m2 + 16.f * dd) * (1.0f / 128.0f) + 1e-5f);     // v_rsq_f32, 1 ulp
 }

@@ -202,12 +202,132 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_split_kernel(EdgeArgsB a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// enc_edge, register-prefetch form (used for f16x2, which leaves the VGPRs for it): the next residue's fp32 tile is
+// loaded straight into the accumulator layout (row 16 rb + m, columns 16 wv + 4 q: one 16-byte load per row block)
+// at the top of the iteration, split into the e planes after GEMM 3 and kept in registers as the fp32 residual of the
+// next iteration. No LDS staging, no LDS-DMA (whose conservative vmcnt(0) waits serialised the store phase), biases and
+// LayerNorm parameters live in registers, every global access of the loop is unconditional.
+// ------------------------------------------------------------------------------------------------
+template <typename SP>
+__global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a) {
+    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
+    static_assert(TILEB >= TM_TILE * TM_H * 4, "the fp32 LayerNorm tile is aliased on the x planes");
+    __shared__ __attribute__((aligned(16))) char tE[TILEB];
+    __shared__ __attribute__((aligned(16))) char tX[TILEB];              // x planes; later the fp32 LayerNorm input
+    __shared__ __attribute__((aligned(16))) char tY[TILEB];
+    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
+    __shared__ int s_idx[2][TM_TILE];
+    float *tO = reinterpret_cast<float *>(tX);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+
+    WFragS<SP> w11[1][4], w12[1][4], w13[1][4];
+    load_wfrag_split<SP, 4>(a.W11e, 384, 16 * wv, 0, TM_H, w11[0], lane);
+    load_wfrag_split<SP, 4>(a.W12, TM_H, 16 * wv, 0, TM_H, w12[0], lane);
+    load_wfrag_split<SP, 4>(a.W13, TM_H, 16 * wv, 0, TM_H, w13[0], lane);
+    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
+    const int c32 = lane & 31;
+    const f4 b12 = ld4(a.b12 + ncol), b13 = ld4(a.b13 + ncol);
+    const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
+
+    const TileRange tr = xcd_tile_range(a.T);
+    int i = tr.begin;
+    int cur = 0;
+    f4 gai, gcj[3], e_cur[3], e_nxt[3];
+    if (i < tr.end) {
+        if (tid < TM_TILE) s_idx[0][tid] = a.E_idx[(size_t)i * TM_KS + tid];
+        const float *src = a.hE + (size_t)i * TM_KS * TM_H + ncol;
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) e_cur[rb] = ld4(src + (16 * rb + m) * TM_H);
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) store_split<SP>(tE, 16 * rb + m, c4, e_cur[rb]);
+        gai = ld4(a.P + (size_t)i * 256 + ncol);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int j = s_idx[0][16 * rb + m];
+            gcj[rb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol);
+        }
+        __syncthreads();
+    }
+    for (; i < tr.end; i += tr.step) {
+        float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
+        const int inext = i + tr.step;
+        const bool has_next = inext < tr.end;
+        const int ipf = has_next ? inext : i;              // prefetch target (the last iteration re-reads its own tile)
+        int nidx = -1;
+        {
+            const float *src = a.hE + (size_t)ipf * TM_KS * TM_H + ncol;
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = ld4(src + (16 * rb + m) * TM_H);
+            if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf * TM_KS + tid];
+        }
+        f4 acc[3][1];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
+        mma_tile_split<SP, 4, 1>(tE, w11, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            store_split<SP>(tX, 16 * rb + m, c4, gelu4(acc[rb][0]));
+            __builtin_amdgcn_sched_barrier(0);      // one row block at a time: keeps the GELU temporaries out of the weight VGPRs
+        }
+        if (tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx;
+        __syncthreads();
+
+        gai = ld4(a.P + (size_t)ipf * 256 + ncol);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int j = s_idx[cur ^ 1][16 * rb + m];
+            gcj[rb] = ld4(a.P + (size_t)(j < 0 ? ipf : j) * 256 + 128 + ncol);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
+        mma_tile_split<SP, 4, 1>(tX, w12, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            store_split<SP>(tY, 16 * rb + m, c4, gelu4(acc[rb][0]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
+        mma_tile_split<SP, 4, 1>(tY, w13, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const f4 v = e_cur[rb] + acc[rb][0];                             // residual on the fp32 tile
+            st4(tO + chunk_off(16 * rb + m, c4), v);
+            row_stats_partial1b(v, &s_stat[16 * rb + m][2 * wv], q);
+        }
+        __syncthreads();                                                     // tE free, tO + stats complete
+
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            store_split<SP>(tE, 16 * rb + m, c4, e_nxt[rb]);
+            e_cur[rb] = e_nxt[rb];
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int row = 6 * wv + 2 * it + (lane >> 5);
+            float mean, rstd;
+            row_stats_finish8b(&s_stat[row][0], mean, rstd);
+            const f4 y = (ld4(tO + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
+            // rows without a neighbour keep the zeros the featurizer wrote: store zeros again (no divergent branch)
+            st4(tile_g + (size_t)row * TM_H + 4 * c32, s_idx[cur][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
 int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
     EdgeArgsB a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
+    static const bool dma = [] { const char *e = getenv("TMPNN_SPLIT_DMA"); return e != nullptr && e[0] == '1'; }();
     if (mode == TM_MM_BF16X3) enc_edge8_split_kernel<SplitBF3><<<grid, 512, 0, st>>>(a);
-    else enc_edge8_split_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
+    else if (dma) enc_edge8_split_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
+    else enc_edge8_rp_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
     return tm_check_launch("enc_edge_split");
 }
 
@@ -346,6 +466,114 @@ __global__ __launch_bounds__(512, 2) void msg8_split_kernel(MsgArgsB a) {
     }
 }
 
+// Register-prefetch form of the message kernel (f16x2): the next residue's fp32 tile is loaded in the accumulator
+// layout at the top of the iteration and split into the e planes once GEMM 1 has consumed the current ones.
+template <typename SP, bool DEC>
+__global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
+    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
+    __shared__ __attribute__((aligned(16))) char tE[TILEB];
+    __shared__ __attribute__((aligned(16))) char tA[TILEB];
+    __shared__ __attribute__((aligned(16))) float tS[TM_TILE * TM_H];
+    __shared__ float s_part[3][TM_H];
+    __shared__ int s_idx[2][TM_TILE];
+    __shared__ float s_ma[2][TM_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+
+    WFragS<SP> w1[1][4], w2[1][4];
+    load_wfrag_split<SP, 4>(a.W1e, a.ld1, 16 * wv, 0, TM_H, w1[0], lane);
+    load_wfrag_split<SP, 4>(a.W2, TM_H, 16 * wv, 0, TM_H, w2[0], lane);
+    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
+    const f4 bias2 = ld4(a.b2 + ncol);
+
+    auto stage_idx = [&](int ii, int buf) {           // neighbour list + attention mask of residue ii -> LDS
+        if (tid < TM_TILE) {
+            const int j = a.E_idx[(size_t)ii * TM_KS + tid];
+            s_idx[buf][tid] = j;
+            s_ma[buf][tid] = j < 0 ? 0.f : (DEC ? 1.f : a.mask[ii] * a.mask[j]);
+        }
+    };
+    f4 g0, gj[3], e_nxt[3];
+    auto gather = [&](int ii, int buf) {
+        g0 = ld4(a.P + (size_t)ii * 256 + ncol);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int j0 = s_idx[buf][16 * rb + m];
+            const int j = j0 < 0 ? ii : j0;
+            gj[rb] = ld4(a.P + (size_t)j * 256 + 128 + ncol);
+            if (DEC) gj[rb] += ld4(a.seq_table + a.S[j] * TM_H + ncol);
+        }
+    };
+    auto fetch_tile = [&](int ii) {
+        const float *src = a.hE + (size_t)ii * TM_KS * TM_H + ncol;
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = ld4(src + (16 * rb + m) * TM_H);
+    };
+    auto split_tile = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) store_split<SP>(tE, 16 * rb + m, c4, e_nxt[rb]);
+    };
+
+    const TileRange tr = xcd_tile_range(a.T);
+    int i = tr.begin;
+    int cur = 0;
+    if (i < tr.end) {
+        stage_idx(i, 0);
+        fetch_tile(i);
+        __syncthreads();
+        split_tile();
+        gather(i, 0);
+        __syncthreads();
+    }
+    for (; i < tr.end; i += tr.step) {
+        const int inext = i + tr.step;
+        const int ipf = inext < tr.end ? inext : i;             // the last iteration prefetches its own tile again
+        const float mi = a.mask[i];
+        fetch_tile(ipf);
+        stage_idx(ipf, cur ^ 1);
+        f4 acc[3][1];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
+        mma_tile_split<SP, 4, 1>(tE, w1, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            f4 v = acc[rb][0];
+            if (DEC) v = g0 + mi * v;
+            store_split<SP>(tA, 16 * rb + m, c4, gelu4(v));
+        }
+        __syncthreads();                                         // tE consumed; tA, s_idx/s_ma[next] complete
+
+        split_tile();
+        gather(ipf, cur ^ 1);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = bias2;
+        mma_tile_split<SP, 4, 1>(tA, w2, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const float ma = s_ma[cur][16 * rb + m];
+            f4 v = gelu4(acc[rb][0]) * ma;
+            if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
+            st4(tS + chunk_off(16 * rb + m, c4), v);
+        }
+        if (tid == 128) {                                        // neighbour count of this tile (read before s_ma[cur] is recycled)
+            float c = 0.f;
+            for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
+            a.cnt[i] = c;
+        }
+        __syncthreads();
+        {   // per-node aggregation: column sums over 4 row groups of 12, combined in a fixed order
+            const int n = tid & 127, grp = tid >> 7;
+            float s = 0.f;
+#pragma unroll
+            for (int r = 12 * grp; r < 12 * grp + 12; ++r) s += tS[chunk_off(r, n >> 2) + (n & 3)];
+            if (grp) s_part[grp - 1][n] = s;
+            __syncthreads();
+            if (!grp) a.Ssum[(size_t)i * TM_H + n] = ((s + s_part[0][n]) + s_part[1][n]) + s_part[2][n];
+        }
+        cur ^= 1;
+        // no barrier here (see msg8_split_kernel)
+    }
+}
+
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                    const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
                    int64_t T, float *Ssum, float *cnt, hipStream_t st) {
@@ -356,8 +584,14 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
         if (dec) msg8_split_kernel<SplitBF3, true><<<grid, 512, 0, st>>>(a);
         else msg8_split_kernel<SplitBF3, false><<<grid, 512, 0, st>>>(a);
     } else {
-        if (dec) msg8_split_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
-        else msg8_split_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
+        static const bool dma = [] { const char *e = getenv("TMPNN_SPLIT_DMA"); return e != nullptr && e[0] == '1'; }();
+        if (dma) {
+            if (dec) msg8_split_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
+            else msg8_split_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
+        } else {
+            if (dec) msg8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
+            else msg8_rp_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
+        }
     }
     return tm_check_launch(dec ? "dec_msg_split" : "enc_msg_split");
 }
