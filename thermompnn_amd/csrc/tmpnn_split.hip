@@ -503,14 +503,17 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
             if (DEC) gj[rb] += ld4(a.seq_table + a.S[j] * TM_H + ncol);
         }
     };
+    // row layout: one half-wavefront per 512-byte row, fully coalesced (the message kernels never need the tile in
+    // the accumulator layout)
+    const int prow = 6 * wv + (lane >> 5), pc = lane & 31;
     auto fetch_tile = [&](int ii) {
-        const float *src = a.hE + (size_t)ii * TM_KS * TM_H + ncol;
+        const float *src = a.hE + ((size_t)ii * TM_KS + prow) * TM_H + 4 * pc;
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = ld4(src + (16 * rb + m) * TM_H);
+        for (int it = 0; it < 3; ++it) e_nxt[it] = ld4(src + 2 * it * TM_H);
     };
     auto split_tile = [&]() {
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) store_split<SP>(tE, 16 * rb + m, c4, e_nxt[rb]);
+        for (int it = 0; it < 3; ++it) store_split<SP>(tE, prow + 2 * it, pc, e_nxt[it]);
     };
 
     const TileRange tr = xcd_tile_range(a.T);
