@@ -306,12 +306,12 @@ static int carve_layer_ws(void *workspace, size_t bytes, int64_t T, LayerWs *ws,
 // pass, or decoder layer 0's after the last encoder layer; decoder layer l+1's after decoder layer l.
 static NodeProj enc_msg_proj(const tmpnn_weights *w, int l, float *P) {
     const EncW &e = w->enc[l];
-    return NodeProj{e.W1, 384, e.b1, e.W1 + 256, 384, P};
+    return NodeProj{e.W1, 384, e.b1, e.W1 + 256, 384, P, nullptr, nullptr};
 }
-static NodeProj dec_msg_proj(const tmpnn_weights *w, int l, float *P) {
-    // W1 columns: [0:128) h_i | [128:256) e_ij | [256:384) W_s[S_j] (folded into seq_table) | [384:512) h_j
+static NodeProj dec_msg_proj(const tmpnn_weights *w, int l, float *P, const int32_t *S) {
+    // W1 columns: [0:128) h_i | [128:256) e_ij | [256:384) W_s[S_j] (folded into seq_table, added to the h_j term) | [384:512) h_j
     const DecW &d = w->dec[l];
-    return NodeProj{d.W1, 512, d.b1, d.W1 + 384, 512, P};
+    return NodeProj{d.W1, 512, d.b1, d.W1 + 384, 512, P, w->seq_table[l], S};
 }
 
 // have_P: ws.P already holds this layer's message projection (written by the previous node_update)
@@ -320,11 +320,11 @@ static int run_enc_layer(const tmpnn_weights *w, int l, float *hV, float *hE, co
     const EncW &e = w->enc[l];
     if (!have_P) {
         const NodeProj mp = enc_msg_proj(w, l, ws.P);
-        TRY(launch_node_proj(hV, mp.Wa, mp.lda, mp.ba, mp.Wc, mp.ldc, T, ws.P, st));
+        TRY(launch_node_proj(hV, mp, T, st));
     }
     // message + node update (EncLayer :819-832); the update also projects the NEW state for the edge update
-    TRY(launch_msg(false, e.W1 + 128, 384, e.W2, e.b2, ws.P, nullptr, nullptr, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
-    const NodeProj ep{e.W11, 384, e.b11, e.W11 + 256, 384, ws.P2};
+    TRY(launch_msg(false, e.W1 + 128, 384, e.W2, e.b2, ws.P, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
+    const NodeProj ep{e.W11, 384, e.b11, e.W11 + 256, 384, ws.P2, nullptr, nullptr};
     TRY(launch_node_update(e.W3, e.b3, e.norm1_w, e.norm1_b, e.Win, e.bin, e.Wout, e.bout, e.norm2_w, e.norm2_b, hV,
                            ws.Ssum, ws.cnt, mask, T, hV, &ep, next, st));
     // edge update with the NEW node states (:834-838)
@@ -337,10 +337,10 @@ static int run_dec_layer(const tmpnn_weights *w, int l, const float *hV_in, floa
                          bool have_P, const NodeProj *next, hipStream_t st) {
     const DecW &d = w->dec[l];
     if (!have_P) {
-        const NodeProj mp = dec_msg_proj(w, l, ws.P);
-        TRY(launch_node_proj(hV_in, mp.Wa, mp.lda, mp.ba, mp.Wc, mp.ldc, T, ws.P, st));
+        const NodeProj mp = dec_msg_proj(w, l, ws.P, S);
+        TRY(launch_node_proj(hV_in, mp, T, st));
     }
-    TRY(launch_msg(true, d.W1 + 128, 512, d.W2, d.b2, ws.P, w->seq_table[l], S, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
+    TRY(launch_msg(true, d.W1 + 128, 512, d.W2, d.b2, ws.P, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
     TRY(launch_node_update(d.W3, d.b3, d.norm1_w, d.norm1_b, d.Win, d.bin, d.Wout, d.bout, d.norm2_w, d.norm2_b, hV_in,
                            ws.Ssum, ws.cnt, mask, T, hV_out, next, nullptr, st));
     return TMPNN_OK;
@@ -498,11 +498,11 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     // node_update of every layer also writes the projection the next message pass needs into ws.P, so only the
     // very first projection (of the all-zero state) is a separate launch: 20 launches per forward instead of 28
     for (int l = 0; l < 3; ++l) {
-        const NodeProj next = l < 2 ? enc_msg_proj(w, l + 1, ws.P) : dec_msg_proj(w, 0, ws.P);
+        const NodeProj next = l < 2 ? enc_msg_proj(w, l + 1, ws.P) : dec_msg_proj(w, 0, ws.P, S);
         TRY(run_enc_layer(w, l, hV[0], hE, E_idx, mask, T, ws, l > 0, &next, st));
     }
     for (int l = 0; l < 3; ++l) {
-        const NodeProj next = dec_msg_proj(w, l < 2 ? l + 1 : 2, ws.P);
+        const NodeProj next = dec_msg_proj(w, l < 2 ? l + 1 : 2, ws.P, S);
         TRY(run_dec_layer(w, l, hV[l], hV[l + 1], hE, E_idx, S, mask, T, ws, true, l < 2 ? &next : nullptr, st));
     }
     if (ddg) TRY(launch_head(w, hV[3], hV[2], S, T, ddg, nullptr, st));

@@ -97,8 +97,9 @@ __device__ __forceinline__ float gelu1(float x) {
 // (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes-worth of fp32 per issue slot) — same arithmetic as gelu1.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 gelu2(f2 x) {
-    f2 t = f2{fabsf(x.x), fabsf(x.y)} * 0.70710678118654752440f;
-    t = f2{fminf(t.x, 4.0f), fminf(t.y, 4.0f)};
+    // |x| rides on the multiply as a source modifier; x Phi(x) = max(x, 0) - |x| h  (h = 0.5 erfc(|x|/sqrt2)) needs no
+    // sign transfer: one v_max and one v_fma (with -|x| modifiers) per value
+    const f2 t = f2{fminf(fabsf(x.x) * 0.70710678118654752440f, 4.0f), fminf(fabsf(x.y) * 0.70710678118654752440f, 4.0f)};
     f2 q = f2{2.814671218e-06f, 2.814671218e-06f};
     q = __builtin_elementwise_fma(q, t, f2{-5.093904975e-05f, -5.093904975e-05f});
     q = __builtin_elementwise_fma(q, t, f2{3.626021436e-04f, 3.626021436e-04f});
@@ -109,9 +110,8 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
     q = __builtin_elementwise_fma(q, t, f2{-9.183712091e-01f, -9.183712091e-01f});
     q = __builtin_elementwise_fma(q, t, f2{-1.627908858e+00f, -1.627908858e+00f});
     const f2 e = __builtin_elementwise_fma(q, t, f2{-1.0f, -1.0f});
-    const f2 d = 0.5f - f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-    const f2 c = f2{copysignf(d.x, x.x), copysignf(d.y, x.y)};
-    return x * (0.5f + c);
+    return f2{fmaf(-fabsf(x.x), __builtin_amdgcn_exp2f(e.x), fmaxf(x.x, 0.f)),
+              fmaf(-fabsf(x.y), __builtin_amdgcn_exp2f(e.y), fmaxf(x.y, 0.f))};
 }
 __device__ __forceinline__ f4 gelu4(f4 v) {
     const f2 a = gelu2(f2{v.x, v.y}), b = gelu2(f2{v.z, v.w});
@@ -224,6 +224,16 @@ __device__ __forceinline__ void load_tile_async(float *tile, const float *__rest
             (__attribute__((address_space(3))) void *)(tile + rp * 2 * TM_H), 16, 0, 0);
     }
 }
+
+// LDS-DMA issued through inline asm: hipcc treats the builtin above conservatively (s_waitcnt vmcnt(0) in front of the
+// first LDS read after it — the copy ends up synchronous). Here the wait is ours to place: lds_dma_wait() before the
+// barrier that publishes the data. Hidden VM operations only make the compiler's own vmcnt(N) waits more conservative.
+// One call copies 64 x 16 B: lane l's 16 bytes at `g` land at lds_wave_base + 16 l.
+__device__ __forceinline__ void lds_dma16(const float *g, const void *lds_wave_base) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 lanes of a half-wavefront
     v += __shfl_xor(v, 16);

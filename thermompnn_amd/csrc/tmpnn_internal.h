@@ -56,12 +56,12 @@ int launch_gather_rows(const float *nodes, const void *idx, int idx64, int64_t n
 int launch_gather_edges(const float *edges, const int64_t *idx, int B, int N, int K, int C, float *out, hipStream_t st);
 
 // tmpnn_layers.hip
-int launch_node_proj(const float *h, const float *Wa, int lda, const float *ba, const float *Wc, int ldc, int64_t T,
-                     float *P, hipStream_t st);
 int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
-               const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
-               int64_t T, float *Ssum, float *cnt, hipStream_t st);
-struct NodeProj { const float *Wa; int lda; const float *ba; const float *Wc; int ldc; float *P; };   // P [T,256]
+               const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt, hipStream_t st);
+// P [T,256]: P[t, 0:128] = Wa h_t + ba, P[t, 128:256] = Wc h_t (+ add_tab[add_idx[t]] when add_tab is set: the decoder's
+// sequence term W1[:, 256:384] W_s[S_t], which rides with the neighbour's projection)
+struct NodeProj { const float *Wa; int lda; const float *ba; const float *Wc; int ldc; float *P; const float *add_tab; const int32_t *add_idx; };
+int launch_node_proj(const float *h, const NodeProj &np, int64_t T, hipStream_t st);
 int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
                        const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,
@@ -79,8 +79,7 @@ int launch_clock_probe(int blocks, int iters, unsigned long long *out, float *si
 // tmpnn_split.hip (mode = TM_MM_F16X2 | TM_MM_BF16X3)
 int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
-                     const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
-                     int64_t T, float *Ssum, float *cnt, hipStream_t st);
+                     const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt, hipStream_t st);
 int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, hipStream_t st);
 
 int tm_num_cus();

@@ -22,7 +22,9 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_proj_kernel(const float *_
                                                                   const float *__restrict__ Wa, int lda,
                                                                   const float *__restrict__ ba,
                                                                   const float *__restrict__ Wc, int ldc, int T,
-                                                                  float *__restrict__ P) {
+                                                                  float *__restrict__ P,
+                                                                  const float *__restrict__ add_tab,
+                                                                  const int32_t *__restrict__ add_idx) {
     __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     float wa[2][32], wc[2][32];
@@ -52,9 +54,12 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_proj_kernel(const float *_
             for (int rb = 0; rb < 3; ++rb) {
                 const int row = r0 + 16 * rb + m;
                 if (row < T) {
+                    const float *add = half && add_tab ? add_tab + add_idx[row] * TM_H : nullptr;
 #pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-                        st4(P + (size_t)row * 256 + 128 * half + 32 * wv + 16 * cb + 4 * q, acc[rb][cb]);
+                    for (int cb = 0; cb < 2; ++cb) {
+                        const int n = 32 * wv + 16 * cb + 4 * q;
+                        st4(P + (size_t)row * 256 + 128 * half + n, add ? ld4(add + n) + acc[rb][cb] : acc[rb][cb]);
+                    }
                 }
             }
         }
@@ -66,13 +71,12 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_proj_kernel(const float *_
 // msg: per residue i (tile = its 48 neighbour slots):  Ssum_i = sum_k ma_ik * gelu(W2 gelu(pre_ik) + b2)
 //   encoder: pre = A_i + C_j + W1b e_ij                  ma = mask_i mask_j   (EncLayer :819-825, :1232-1233)
 //   decoder: pre = A_i + mask_i (W1b e_ij + SeqT[S_j] + D_j)   ma = 1         (DecLayer :863-870, :1270-1272)
+//            (SeqT[S_j] + D_j arrives pre-added in the neighbour half of P: NodeProj::add_tab)
 // ------------------------------------------------------------------------------------------------
 struct MsgArgs {
     const float *W1e; int ld1;
     const float *W2, *b2;
-    const float *P;          // [T,256]: A (bias folded) | C or D
-    const float *seq_table;  // [21,128] decoder only
-    const int32_t *S;
+    const float *P;          // [T,256]: A (bias folded) | C or D (+ sequence term)
     const float *hE;         // [T,48,128]
     const int32_t *E_idx;    // [T,48]
     const float *mask;       // [T]
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void msg_kernel(MsgArgs a) {
             if (DEC) {   // the gathered terms ride in the accumulator: their L2 latency hides under the GEMM
 #pragma unroll
                 for (int rb = 0; rb < 3; ++rb)
-                    acc[rb][cb] = ld4(a.seq_table + a.S[jrow[rb]] * TM_H + n) + ld4(a.P + (size_t)jrow[rb] * 256 + 128 + n);
+                    acc[rb][cb] = ld4(a.P + (size_t)jrow[rb] * 256 + 128 + n);
             } else {
                 const f4 ai = ld4(a.P + (size_t)i * 256 + n);
 #pragma unroll
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void enc_edge_pp_kernel(EdgeArgs a) 
 // launches and two re-reads of h per layer. Tile = 16*NRB residues: 48 for batches, 16 when T is small so that a
 // single protein still spreads over more CUs (the weights stream from L2 either way).
 // ------------------------------------------------------------------------------------------------
-struct ProjSpec { const float *Wa; int lda; const float *ba; const float *Wc; int ldc; float *P; };
+struct ProjSpec { const float *Wa; int lda; const float *ba; const float *Wc; int ldc; float *P; const float *add_tab; const int32_t *add_idx; };
 struct NodeArgs {
     const float *W3, *b3, *n1w, *n1b, *Win, *bin, *Wout, *bout, *n2w, *n2b;
     const float *h_in, *Ssum, *cnt, *mask;
@@ -919,9 +923,12 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_update_kernel(NodeArgs a) 
                 for (int rb = 0; rb < NRB; ++rb) {
                     const int row = r0 + 16 * rb + m;
                     if (row < a.T) {
+                        const float *add = half && ps.add_tab ? ps.add_tab + ps.add_idx[row] * TM_H : nullptr;
 #pragma unroll
-                        for (int cb = 0; cb < 2; ++cb)
-                            st4(ps.P + (size_t)row * 256 + 128 * half + 32 * wv + 16 * cb + 4 * q, acc[rb][cb]);
+                        for (int cb = 0; cb < 2; ++cb) {
+                            const int n = 32 * wv + 16 * cb + 4 * q;
+                            st4(ps.P + (size_t)row * 256 + 128 * half + n, add ? ld4(add + n) + acc[rb][cb] : acc[rb][cb]);
+                        }
                     }
                 }
             }
@@ -938,22 +945,20 @@ static int grid_for(int64_t work_items, int blocks_per_cu) {
     return (int)(work_items < cap ? (work_items < 1 ? 1 : work_items) : cap);
 }
 
-int launch_node_proj(const float *h, const float *Wa, int lda, const float *ba, const float *Wc, int ldc, int64_t T,
-                     float *P, hipStream_t st) {
+int launch_node_proj(const float *h, const NodeProj &np, int64_t T, hipStream_t st) {
     const int64_t tiles = (T + TM_TILE - 1) / TM_TILE;
-    { tm_prof_begin("node_proj", st); node_proj_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(h, Wa, lda, ba, Wc, ldc, (int)T, P); tm_prof_end(st); }
+    { tm_prof_begin("node_proj", st); node_proj_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(h, np.Wa, np.lda, np.ba, np.Wc, np.ldc, (int)T, np.P, np.add_tab, np.add_idx); tm_prof_end(st); }
     return tm_check_launch("node_proj");
 }
 
 int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
-               const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
-               int64_t T, float *Ssum, float *cnt, hipStream_t st) {
-    MsgArgs a{W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, Ssum, cnt, (int)T, 0};
+               const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt, hipStream_t st) {
+    MsgArgs a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T, 0};
     static const int nw = [] { const char *e = getenv("TMPNN_MSG_WAVES"); return e ? atoi(e) : 4; }();
     const int grid = grid_for(T, 2);
     tm_prof_begin(dec ? "dec_msg" : "enc_msg", st);
     if (tm_matmul_mode() != TM_MM_FP32) {
-        const int rc = launch_msg_split(tm_matmul_mode(), dec, W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, T, Ssum, cnt, st);
+        const int rc = launch_msg_split(tm_matmul_mode(), dec, W1e, ld1, W2, b2, P, hE, E_idx, mask, T, Ssum, cnt, st);
         tm_prof_end(st);
         return rc;
     }
@@ -1018,8 +1023,8 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
     NodeArgs a{W3, b3, n1w, n1b, Win, bin, Wout, bout, n2w, n2b, h_in, Ssum, cnt, mask, h_out, (int)T, {}};
     const NodeProj *ps[2] = {p0, p1};
     for (int k = 0; k < 2; ++k)
-        a.proj[k] = ps[k] ? ProjSpec{ps[k]->Wa, ps[k]->lda, ps[k]->ba, ps[k]->Wc, ps[k]->ldc, ps[k]->P}
-                          : ProjSpec{nullptr, 0, nullptr, nullptr, 0, nullptr};
+        a.proj[k] = ps[k] ? ProjSpec{ps[k]->Wa, ps[k]->lda, ps[k]->ba, ps[k]->Wc, ps[k]->ldc, ps[k]->P, ps[k]->add_tab, ps[k]->add_idx}
+                          : ProjSpec{nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     tm_prof_begin("node_update", st);
     // Tile height (16 / 32 / 48 residues) chosen for load balance: the grid offers 2 workgroup slots per CU, every
     // tile streams the same ~0.8 MB of weights from L2 (worth about 16 rows of MFMA time), so minimise

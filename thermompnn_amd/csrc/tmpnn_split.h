@@ -194,6 +194,28 @@ __device__ __forceinline__ void mma_tile_split(const char *tile, const WFragS<SP
         for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = SP::fold(acc[rb][cb], lo[rb][cb]);
 }
 
+// One 16-row block at a time (keeps only NCB accumulator pairs live): acc[cb] += W_cb . tile[16 rb .. 16 rb + 16)^T.
+// (Interleaving the MFMA chains term by term across accumulators was measured: no gain in the kernels, -12 % in the
+// GEMM probe — back-to-back MFMAs on one accumulator do not stall on gfx950.)
+template <typename SP, int NK32, int NCB, int ROWS = TM_TILE, int ROWB = 256>
+__device__ __forceinline__ void mma_rb_split(const char *tile, int rb, const WFragS<SP> (&w)[NCB][NK32], f4 (&acc)[NCB], int lane) {
+    const int m = lane & 15, q = lane >> 4;
+    f4 lo[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) lo[cb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NK32; ++c) {
+        u4 x[SP::NP];
+#pragma unroll
+        for (int p = 0; p < SP::NP; ++p)
+            x[p] = *reinterpret_cast<const u4 *>(tile + plane_off8<ROWS, ROWB>(p, 16 * rb + m, 4 * c + q));
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) SP::mma(w[cb][c].p, x, acc[cb], lo[cb]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = SP::fold(acc[cb], lo[cb]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm statistics fused into a GEMM epilogue (8 wavefronts x 16 columns): each wavefront reduces its 16 columns
 // of a row to (mean, M2) over the 4 lane quarters (Chan merge), the 8 partials per row meet in LDS [row][16].

@@ -338,8 +338,7 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
 // ------------------------------------------------------------------------------------------------
 struct MsgArgsB {
     const float *W1e; int ld1;
-    const float *W2, *b2, *P, *seq_table;
-    const int32_t *S;
+    const float *W2, *b2, *P;
     const float *hE;
     const int32_t *E_idx;
     const float *mask;
@@ -395,7 +394,6 @@ __global__ __launch_bounds__(512, 2) void msg8_split_kernel(MsgArgsB a) {
             const int j0 = s_idx[buf][16 * rb + m];
             const int j = j0 < 0 ? ii : j0;
             gj[rb] = ld4(a.P + (size_t)j * 256 + 128 + ncol);
-            if (DEC) gj[rb] += ld4(a.seq_table + a.S[j] * TM_H + ncol);
         }
     };
 
@@ -500,7 +498,6 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
             const int j0 = s_idx[buf][16 * rb + m];
             const int j = j0 < 0 ? ii : j0;
             gj[rb] = ld4(a.P + (size_t)j * 256 + 128 + ncol);
-            if (DEC) gj[rb] += ld4(a.seq_table + a.S[j] * TM_H + ncol);
         }
     };
     // row layout: one half-wavefront per 512-byte row, fully coalesced (the message kernels never need the tile in
@@ -531,17 +528,26 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
         const int inext = i + tr.step;
         const int ipf = inext < tr.end ? inext : i;             // the last iteration prefetches its own tile again
         const float mi = a.mask[i];
+        // neighbour list of the next residue: loaded first, its dependent mask gather issued behind GEMM 1, both
+        // published to LDS only after the epilogue — no wavefront ever sits on a global-load latency in front of its MFMAs
+        int nidx = -1;
+        if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf * TM_KS + tid];
         fetch_tile(ipf);
-        stage_idx(ipf, cur ^ 1);
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
         mma_tile_split<SP, 4, 1>(tE, w1, acc, lane);
+        float nma = 0.f;
+        if (tid < TM_TILE && nidx >= 0) nma = DEC ? 1.f : a.mask[ipf] * a.mask[nidx];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             f4 v = acc[rb][0];
             if (DEC) v = g0 + mi * v;
             store_split<SP>(tA, 16 * rb + m, c4, gelu4(v));
+        }
+        if (tid < TM_TILE) {
+            s_idx[cur ^ 1][tid] = nidx;
+            s_ma[cur ^ 1][tid] = nma;
         }
         __syncthreads();                                         // tE consumed; tA, s_idx/s_ma[next] complete
 
@@ -577,10 +583,145 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
     }
 }
 
+// 4-wavefront form (f16x2): each wavefront owns 32 output columns (two column blocks, 128 weight VGPRs), one row
+// block in flight at a time; two workgroups share a CU, so one workgroup's GELU/split (VALU) phases run under the
+// other's MFMA phases — a wavefront cannot overlap the two by itself — and every B-fragment read feeds two MFMA chains.
+// The next residue's fp32 tile lands in an LDS staging buffer by (inline-asm) LDS-DMA under GEMM 1. The masked sum over
+// the K neighbours is taken in registers (row blocks added per lane, then a 16-lane butterfly), so there is no fp32
+// message tile, no aggregation phase and only two barriers per residue.
+template <typename SP, bool DEC>
+__global__ __launch_bounds__(256, 2) void msg4_rp_kernel(MsgArgsB a) {
+    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
+    __shared__ __attribute__((aligned(16))) char tE[TILEB];
+    __shared__ __attribute__((aligned(16))) char tA[TILEB];
+    __shared__ __attribute__((aligned(16))) float tStage[TM_TILE * TM_H];
+    __shared__ int s_idx[2][TM_TILE];
+    __shared__ float s_ma[2][TM_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+
+    WFragS<SP> w1[2][4], w2[2][4];
+    f4 bias2[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        load_wfrag_split<SP, 4>(a.W1e, a.ld1, 32 * wv + 16 * cb, 0, TM_H, w1[cb], lane);
+        load_wfrag_split<SP, 4>(a.W2, TM_H, 32 * wv + 16 * cb, 0, TM_H, w2[cb], lane);
+        bias2[cb] = ld4(a.b2 + 32 * wv + 16 * cb + 4 * q);
+    }
+    const int ncol = 32 * wv + 4 * q, c4 = 8 * wv + q;      // column block cb adds 16 columns / 4 chunks
+
+    auto stage_idx = [&](int ii, int buf) {           // neighbour list + attention mask of residue ii -> LDS
+        if (tid < TM_TILE) {
+            const int j = a.E_idx[(size_t)ii * TM_KS + tid];
+            s_idx[buf][tid] = j;
+            s_ma[buf][tid] = j < 0 ? 0.f : (DEC ? 1.f : a.mask[ii] * a.mask[j]);
+        }
+    };
+    f4 g0[2], gj[3][2];
+    auto gather = [&](int ii, int buf) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) g0[cb] = ld4(a.P + (size_t)ii * 256 + ncol + 16 * cb);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int j0 = s_idx[buf][16 * rb + m];
+            const int j = j0 < 0 ? ii : j0;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                gj[rb][cb] = ld4(a.P + (size_t)j * 256 + 128 + ncol + 16 * cb);
+            }
+        }
+    };
+    auto stage_async = [&](int ii) {                  // linear copy of one fp32 tile: 24 x 1 KB, six per wavefront
+        const float *src = a.hE + (size_t)ii * TM_KS * TM_H;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int blk = 6 * wv + k;
+            lds_dma16(src + blk * 256 + lane * 4, tStage + blk * 256);
+        }
+    };
+    auto split_stage = [&]() {                        // tStage (fp32, linear) -> e planes
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int idx = it * 256 + tid;
+            store_split<SP>(tE, idx >> 5, idx & 31, ld4(tStage + idx * 4));
+            if (it & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const TileRange tr = xcd_tile_range(a.T);
+    int i = tr.begin;
+    int cur = 0;
+    if (i < tr.end) {
+        stage_idx(i, 0);
+        stage_async(i);
+        lds_dma_wait();
+        __syncthreads();
+        split_stage();
+        gather(i, 0);
+        __syncthreads();
+    }
+    for (; i < tr.end; i += tr.step) {
+        const int inext = i + tr.step;
+        const int ipf = inext < tr.end ? inext : i;             // the last iteration prefetches its own tile again
+        const float mi = a.mask[i];
+        stage_async(ipf);
+        stage_idx(ipf, cur ^ 1);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            f4 acc[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[cb] = DEC ? gj[rb][cb] : g0[cb] + gj[rb][cb];
+            mma_rb_split<SP, 4, 2>(tE, rb, w1, acc, lane);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                f4 v = acc[cb];
+                if (DEC) v = g0[cb] + mi * v;
+                store_split<SP>(tA, 16 * rb + m, c4 + 4 * cb, gelu4(v));
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // one row block at a time
+        }
+        lds_dma_wait();
+        __syncthreads();                                         // tE consumed; tA, tStage, s_idx/s_ma[next] complete
+
+        split_stage();
+        gather(ipf, cur ^ 1);
+        f4 tot[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            f4 acc[2] = {bias2[0], bias2[1]};
+            mma_rb_split<SP, 4, 2>(tA, rb, w2, acc, lane);
+            const float ma = s_ma[cur][16 * rb + m];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                f4 v = gelu4(acc[cb]) * ma;
+                if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
+                tot[cb] += v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int off = 1; off <= 8; off <<= 1)                   // sum over the 16 rows of the lane group (fixed order)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tot[cb][k] += __shfl_xor(tot[cb][k], off);
+        if (m == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) st4(a.Ssum + (size_t)i * TM_H + ncol + 16 * cb, tot[cb]);
+        }
+        if (tid == 128) {                                        // neighbour count of this tile
+            float c = 0.f;
+            for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
+            a.cnt[i] = c;
+        }
+        cur ^= 1;
+        __syncthreads();                                         // tA / tStage consumed, tE complete
+    }
+}
+
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
-                   const float *seq_table, const int32_t *S, const float *hE, const int32_t *E_idx, const float *mask,
-                   int64_t T, float *Ssum, float *cnt, hipStream_t st) {
-    MsgArgsB a{W1e, ld1, W2, b2, P, seq_table, S, hE, E_idx, mask, Ssum, cnt, (int)T};
+                     const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt,
+                     hipStream_t st) {
+    MsgArgsB a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
     if (mode == TM_MM_BF16X3) {
@@ -588,12 +729,20 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
         else msg8_split_kernel<SplitBF3, false><<<grid, 512, 0, st>>>(a);
     } else {
         static const bool dma = [] { const char *e = getenv("TMPNN_SPLIT_DMA"); return e != nullptr && e[0] == '1'; }();
+        // measured on MI355X (same run, 64 x L=256): encoder 4-wavefront form 0.252 vs 0.256 ms, decoder 8-wavefront
+        // form 0.248 vs 0.260 ms -> each layer type gets its faster form unless TMPNN_MSG_WAVES pins one
+        static const int nw_env = [] { const char *e = getenv("TMPNN_MSG_WAVES"); return e ? atoi(e) : 0; }();
+        const int nw = nw_env ? nw_env : (dec ? 8 : 4);
         if (dma) {
             if (dec) msg8_split_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
             else msg8_split_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
-        } else {
+        } else if (nw == 8) {
             if (dec) msg8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
             else msg8_rp_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
+        } else {
+            const int grid2 = (int)(T < 2 * cap ? T : 2 * cap);
+            if (dec) msg4_rp_kernel<SplitH2, true><<<grid2, 256, 0, st>>>(a);
+            else msg4_rp_kernel<SplitH2, false><<<grid2, 256, 0, st>>>(a);
         }
     }
     return tm_check_launch(dec ? "dec_msg_split" : "enc_msg_split");
