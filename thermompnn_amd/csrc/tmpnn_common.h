@@ -233,6 +233,11 @@ __device__ __forceinline__ void lds_dma16(const float *g, const void *lds_wave_b
     const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory", "m0");
 }
+// Pins the point where a loaded value must have arrived. gfx9 counts loads AND stores in one in-order vmcnt: a value
+// first used after later stores were issued makes hipcc wait for those stores too (s_waitcnt vmcnt(N) cannot skip them).
+// Touching the value just before the stores are issued moves the wait to where it is free.
+__device__ __forceinline__ void touch(f4 &v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 lanes of a half-wavefront

@@ -3,6 +3,7 @@
 // Reference semantics: ProteinFeatures (/root/reference/protein_mpnn_utils.py:1084-1180),
 // PositionalEncodings (:896-908), gather_edges (:763-767), gather_nodes (:770-778).
 // Nothing here materialises an L x L matrix: distances are computed per row (kNN) or per edge (RBF).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "tmpnn_common.h"
@@ -268,15 +269,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 1)) void featurize_kernel(F
 
 // ------------------------------------------------------------------------------------------------
 // Split-precision featurizer (default, f16x2): same pipeline, both GEMMs on the 16-bit matrix cores (tmpnn_split.h).
-// The Gaussians are split into planes as they are generated (they never exist as an fp32 tile); the RBF planes are
-// plain row-major with a 848-byte pitch (416 values + 16 B; 212 dwords = 20 banks mod 64, so the 16-row B-fragment
-// reads are conflict-free without a swizzle). Columns 400..415 are zero K-padding. LayerNorm statistics are taken in the
+// The Gaussians are split into planes as they are generated (they never exist as an fp32 tile); the RBF planes have a
+// 1024-byte row pitch (416 values used) with the usual 16-byte-chunk XOR swizzle, which is conflict-free for the
+// ds_read_b128 lane groups of gfx950 (a plain 848-byte pitch measured 42 % conflict cycles). Columns 400..415 are zero K-padding. LayerNorm statistics are taken in the
 // GEMM-1 epilogue (values stay in registers), its output goes straight into the GEMM-2 input planes, which — like the
 // fp32 output tile — are aliased on the dead RBF planes.
 // ------------------------------------------------------------------------------------------------
-#define RBFP_ROWB 848
-template <typename SP>
-__global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
+#define RBFP_ROWB 1024
+// PROF: phase timing (s_memtime deltas of thread 0 of workgroup 0, summed over its tiles) into prof[0..7] — TMPNN_FEAT_PROF=1
+template <typename SP, bool PROF = false>
+__global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, unsigned long long *prof = nullptr) {
+    unsigned long long t_last = 0;
+    auto mark = [&](int k) {
+        if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            if (k >= 0) prof[k] += t - t_last;
+            t_last = t;
+        }
+    };
     constexpr int PLB = TM_TILE * RBFP_ROWB;                 // bytes per RBF plane
     constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
     static_assert(SP::NP * PLB >= TILEB, "the GEMM-2 planes are aliased on the RBF planes");
@@ -304,6 +314,7 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
 
     // Per-tile inputs (neighbour list, 5 atoms of every neighbour, positional index, Ca-Ca distance) are fetched into
     // registers by 49 threads one tile ahead — the dependent global loads (E_idx -> X[j]) fly under GEMM 1.
+    // (A two-deep variant — list of tile i+2, rows of tile i+1 — was measured: no gain; GEMM 1 was LDS-latency bound.)
     float g_at[15];
     float g_d0 = 0.f;
     int g_idx = -1, g_dpos = 0;
@@ -358,12 +369,13 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
         distances();
         __syncthreads();
     }
+    mark(-1);
     for (; i < tr.end; i += tr.step) {
         const int inext = i + tr.step;
         const bool has_next = inext < tr.end;
         if (tid < TM_TILE * 2 * SP::NP) {                       // zero the K padding (columns 400..415) of every plane row
             const int p = tid / (TM_TILE * 2), rem = tid - p * (TM_TILE * 2);
-            *reinterpret_cast<u4 *>(rbf + p * PLB + (rem >> 1) * RBFP_ROWB + 800 + 16 * (rem & 1)) = u4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u4 *>(rbf + plane_off8<TM_TILE, RBFP_ROWB>(p, rem >> 1, 50 + (rem & 1))) = u4{0u, 0u, 0u, 0u};
         }
         for (int e = tid; e < TM_TILE * 100; e += 512) {        // 16 Gaussians per pair, 4 per thread (:1111-1119)
             const int mm = e / 100, c = e - mm * 100;
@@ -379,19 +391,24 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
             SP::split2(f2{v.z, v.w}, hi2);
 #pragma unroll
             for (int p = 0; p < SP::NP; ++p)
-                *reinterpret_cast<u2 *>(rbf + p * PLB + mm * RBFP_ROWB + c * 8) = u2{lo2[p], hi2[p]};
+                *reinterpret_cast<u2 *>(rbf + plane_off4<TM_TILE, RBFP_ROWB>(p, mm, c)) = u2{lo2[p], hi2[p]};
         }
+        mark(0);
         __syncthreads();                                       // RBF planes complete; s_dist / s_atoms consumed
+        mark(1);
 
         if (has_next) fetch(inext);
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_dpos[cur][16 * rb + m] * TM_H + ncol);
-        mma_tile_split<SP, 13, 1, 3, TM_TILE, RBFP_ROWB, 13, 0, false>(rbf, wedge, acc, lane);
+        mma_tile_split<SP, 13, 1, 3, TM_TILE, RBFP_ROWB, 13, 0, true>(rbf, wedge, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) row_stats_partial1b(acc[rb][0], &s_stat[16 * rb + m][2 * wv], q);
+        mark(2);
         if (has_next) publish(cur ^ 1);
+        mark(3);
         __syncthreads();                                       // RBF planes dead, statistics + next tile's atoms complete
+        mark(4);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {                        // norm_edges (:1179)
             const int row = 16 * rb + m;
@@ -401,20 +418,26 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a) {
             store_split<SP>(tAp, row, c4, y);
             if (a.E_opt) st4(a.E_opt + ((size_t)i * TM_KS + row) * TM_H + ncol, s_idx[cur][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
         }
+        mark(5);
         if (has_next) distances();
+        mark(6);
         __syncthreads();
+        mark(7);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = be;
         mma_tile_split<SP, 4, 1>(tAp, we, acc, lane);           // W_e (:1229)
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) st4(tB + chunk_off(16 * rb + m, c4), acc[rb][0]);
+        mark(8);
         __syncthreads();                                       // tAp consumed (the next Gaussians overwrite it), tB complete
+        mark(9);
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int row = 6 * wv + 2 * it + (lane >> 5);
             const f4 y = s_idx[cur][row] >= 0 ? ld4(tB + chunk_off(row, c32)) : f4{0.f, 0.f, 0.f, 0.f};
             st4(a.hE + ((size_t)i * TM_KS + row) * TM_H + 4 * c32, y);
         }
+        mark(10);
         cur ^= 1;
         // no barrier: tB is rewritten only after three more barriers, s_idx[cur^1] after one
     }
@@ -553,6 +576,19 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
     //  much as the shorter 400->128 GEMM saved: 1.07-1.08 ms vs 1.08 ms)
     tm_prof_begin("featurize", st);
     static const bool split_ok = [] { const char *e = getenv("TMPNN_FEAT_SPLIT"); return e == nullptr || e[0] != '0'; }();
+    static const bool feat_prof = [] { const char *e = getenv("TMPNN_FEAT_PROF"); return e != nullptr && e[0] == '1'; }();
+    if (tm_matmul_mode() == TM_MM_F16X2 && split_ok && feat_prof) {       // debug: phase timing of workgroup 0 (synchronises!)
+        static unsigned long long *d_prof = nullptr;
+        if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+        featurize_split_kernel<SplitH2, true><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a, d_prof);
+        unsigned long long h[16];
+        (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "featurize phases (100 MHz ticks, wg 0): gauss %llu bar %llu gemm1+stats %llu publish %llu bar %llu ln+split %llu dist %llu bar %llu gemm2 %llu bar %llu store %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+        tm_prof_end(st);
+        return tm_check_launch("edge_featurize");
+    }
     if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
         featurize_split_kernel<SplitH2><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
         tm_prof_end(st);

@@ -167,8 +167,13 @@ __device__ __forceinline__ void load_wfrag_split(const float *__restrict__ W, in
 // acc[rb][cb] += W_cb . tile^T over K = 32*NK32. The low-order terms go through a second accumulator that is folded
 // in at the end, so they are not swamped while the leading term is still growing. The weight fragments used are
 // w[cb][C0 .. C0+NK32) (a K sub-range of a wider weight); the tile starts at its column 0.
+// PF > 0: explicit software pipeline — the B fragments of step s + PF (a step = one row block of one 32-deep chunk) are
+// requested before the MFMAs of step s, pinned with scheduling barriers; PF < 0: all row blocks of a chunk requested
+// together. Left to itself hipcc, under register pressure, alternates one ds_read with the MFMAs that consume it: the
+// featurizer's 39-step GEMM runs at LDS latency (7.4k cycles against 3.7k of matrix-pipe time). Both forms fix the
+// schedule (6-7 reads in flight) but need 24-32 more VGPRs than that kernel has (81-94 spilled) — not used there yet.
 template <typename SP, int NK32, int NCB, int NRB = 3, int ROWS = TM_TILE, int ROWB = 256, int NKTOT = NK32, int C0 = 0,
-          bool SWZ = true>
+          bool SWZ = true, int PF = 0>
 __device__ __forceinline__ void mma_tile_split(const char *tile, const WFragS<SP> (&w)[NCB][NKTOT], f4 (&acc)[NRB][NCB], int lane) {
     const int m = lane & 15, q = lane >> 4;
     f4 lo[NRB][NCB];
@@ -176,16 +181,57 @@ __device__ __forceinline__ void mma_tile_split(const char *tile, const WFragS<SP
     for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) lo[rb][cb] = f4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PF > 0) {
+        constexpr int NS = NK32 * NRB, NB = PF + 1;
+        u4 x[NB][SP::NP];
 #pragma unroll
-    for (int c = 0; c < NK32; ++c) {
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-            u4 x[SP::NP];                               // one row block at a time: few B-fragment VGPRs in flight
+        for (int s = 0; s < PF && s < NS; ++s)
 #pragma unroll
             for (int p = 0; p < SP::NP; ++p)
-                x[p] = *reinterpret_cast<const u4 *>(tile + plane_off8<ROWS, ROWB, SWZ>(p, 16 * rb + m, 4 * c + q));
+                x[s][p] = *reinterpret_cast<const u4 *>(tile + plane_off8<ROWS, ROWB, SWZ>(p, 16 * (s % NRB) + m, 4 * (s / NRB) + q));
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) SP::mma(w[cb][C0 + c].p, x, acc[rb][cb], lo[rb][cb]);
+        for (int s = 0; s < NS; ++s) {
+            if (s + PF < NS) {
+                const int sn = s + PF;
+#pragma unroll
+                for (int p = 0; p < SP::NP; ++p)
+                    x[sn % NB][p] = *reinterpret_cast<const u4 *>(tile + plane_off8<ROWS, ROWB, SWZ>(p, 16 * (sn % NRB) + m, 4 * (sn / NRB) + q));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) SP::mma(w[cb][C0 + s / NRB].p, x[s % NB], acc[s % NRB][cb], lo[s % NRB][cb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (PF < 0) {
+        // grouped: all NRB row blocks' fragments of a chunk are requested together, then its NRB x NCB x terms MFMAs run
+        // (one LDS latency per chunk instead of one per row block; the SIMD's other wavefront fills the gap)
+#pragma unroll
+        for (int c = 0; c < NK32; ++c) {
+            u4 x[NRB][SP::NP];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int p = 0; p < SP::NP; ++p)
+                    x[rb][p] = *reinterpret_cast<const u4 *>(tile + plane_off8<ROWS, ROWB, SWZ>(p, 16 * rb + m, 4 * c + q));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) SP::mma(w[cb][C0 + c].p, x[rb], acc[rb][cb], lo[rb][cb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NK32; ++c) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                u4 x[SP::NP];                               // one row block at a time: few B-fragment VGPRs in flight
+#pragma unroll
+                for (int p = 0; p < SP::NP; ++p)
+                    x[p] = *reinterpret_cast<const u4 *>(tile + plane_off8<ROWS, ROWB, SWZ>(p, 16 * rb + m, 4 * c + q));
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) SP::mma(w[cb][C0 + c].p, x, acc[rb][cb], lo[rb][cb]);
+            }
         }
     }
 #pragma unroll

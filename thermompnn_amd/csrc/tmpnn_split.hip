@@ -1,4 +1,5 @@
 // Split-precision forms of the per-edge kernels (f16x2 three-term / bf16x3 six-term). See tmpnn_split.h for the arithmetic.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -209,8 +210,16 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_split_kernel(EdgeArgsB a) {
 // next iteration. No LDS staging, no LDS-DMA (whose conservative vmcnt(0) waits serialised the store phase), biases and
 // LayerNorm parameters live in registers, every global access of the loop is unconditional.
 // ------------------------------------------------------------------------------------------------
-template <typename SP>
-__global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a) {
+template <typename SP, bool PROF = false>
+__global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsigned long long *prof = nullptr) {
+    unsigned long long t_last = 0;
+    auto mark = [&](int k) {           // TMPNN_EDGE_PROF=1: phase timing of thread 0 of workgroup 0
+        if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            if (k >= 0) prof[k] += t - t_last;
+            t_last = t;
+        }
+    };
     constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
     static_assert(TILEB >= TM_TILE * TM_H * 4, "the fp32 LayerNorm tile is aliased on the x planes");
     __shared__ __attribute__((aligned(16))) char tE[TILEB];
@@ -248,8 +257,12 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a) {
             const int j = s_idx[0][16 * rb + m];
             gcj[rb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol);
         }
+        touch(gai);                                    // (so that the loop header needs no vmcnt wait of its own)
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) touch(gcj[rb]);
         __syncthreads();
     }
+    mark(-1);
     for (; i < tr.end; i += tr.step) {
         float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
         const int inext = i + tr.step;
@@ -266,13 +279,16 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a) {
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
         mma_tile_split<SP, 4, 1>(tE, w11, acc, lane);
+        mark(0);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             store_split<SP>(tX, 16 * rb + m, c4, gelu4(acc[rb][0]));
             __builtin_amdgcn_sched_barrier(0);      // one row block at a time: keeps the GELU temporaries out of the weight VGPRs
         }
         if (tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx;
+        mark(1);
         __syncthreads();
+        mark(2);
 
         gai = ld4(a.P + (size_t)ipf * 256 + ncol);
 #pragma unroll
@@ -283,29 +299,38 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a) {
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
         mma_tile_split<SP, 4, 1>(tX, w12, acc, lane);
+        mark(3);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             store_split<SP>(tY, 16 * rb + m, c4, gelu4(acc[rb][0]));
             __builtin_amdgcn_sched_barrier(0);
         }
+        mark(4);
         __syncthreads();
+        mark(5);
 
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
         mma_tile_split<SP, 4, 1>(tY, w13, acc, lane);
+        mark(6);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             const f4 v = e_cur[rb] + acc[rb][0];                             // residual on the fp32 tile
             st4(tO + chunk_off(16 * rb + m, c4), v);
             row_stats_partial1b(v, &s_stat[16 * rb + m][2 * wv], q);
         }
+        mark(7);
         __syncthreads();                                                     // tE free, tO + stats complete
+        mark(8);
 
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             store_split<SP>(tE, 16 * rb + m, c4, e_nxt[rb]);
             e_cur[rb] = e_nxt[rb];
         }
+        touch(gai);                                    // the next tile's gathers have long arrived: take their vmcnt wait
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) touch(gcj[rb]); // here, in front of the stores below (see touch())
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int row = 6 * wv + 2 * it + (lane >> 5);
@@ -316,7 +341,9 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a) {
             st4(tile_g + (size_t)row * TM_H + 4 * c32, s_idx[cur][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
         }
         cur ^= 1;
+        mark(9);
         __syncthreads();
+        mark(10);
     }
 }
 
@@ -327,7 +354,21 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
     static const bool dma = [] { const char *e = getenv("TMPNN_SPLIT_DMA"); return e != nullptr && e[0] == '1'; }();
     if (mode == TM_MM_BF16X3) enc_edge8_split_kernel<SplitBF3><<<grid, 512, 0, st>>>(a);
     else if (dma) enc_edge8_split_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
-    else enc_edge8_rp_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
+    else {
+        static const bool prof = [] { const char *e = getenv("TMPNN_EDGE_PROF"); return e != nullptr && e[0] == '1'; }();
+        if (prof) {                                  // debug: phase timing of workgroup 0 (synchronises!)
+            static unsigned long long *d_prof = nullptr;
+            if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
+            (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+            enc_edge8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a, d_prof);
+            unsigned long long h[16];
+            (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "enc_edge phases (cycles, wg 0): gemm1 %llu gelu+split %llu bar %llu gather+gemm2 %llu gelu+split %llu bar %llu gemm3 %llu resid+stats %llu bar %llu split+ln+store %llu bar %llu\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+        } else {
+            enc_edge8_rp_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
+        }
+    }
     return tm_check_launch("enc_edge_split");
 }
 
@@ -663,8 +704,11 @@ __global__ __launch_bounds__(256, 2) void msg4_rp_kernel(MsgArgsB a) {
         const int inext = i + tr.step;
         const int ipf = inext < tr.end ? inext : i;             // the last iteration prefetches its own tile again
         const float mi = a.mask[i];
+        // next residue: neighbour list first, then the tile copy; the list is published behind GEMM 1 and its dependent
+        // mask gather only at the end of the iteration — no wavefront waits on a global load in front of its MFMAs
+        int nidx = -1;
+        if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf * TM_KS + tid];
         stage_async(ipf);
-        stage_idx(ipf, cur ^ 1);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             f4 acc[2];
@@ -680,7 +724,12 @@ __global__ __launch_bounds__(256, 2) void msg4_rp_kernel(MsgArgsB a) {
             __builtin_amdgcn_sched_barrier(0);                   // one row block at a time
         }
         lds_dma_wait();
-        __syncthreads();                                         // tE consumed; tA, tStage, s_idx/s_ma[next] complete
+        float nma = 0.f;
+        if (tid < TM_TILE) {
+            s_idx[cur ^ 1][tid] = nidx;
+            if (nidx >= 0) nma = DEC ? 1.f : a.mask[ipf] * a.mask[nidx];
+        }
+        __syncthreads();                                         // tE consumed; tA, tStage, s_idx[next] complete
 
         split_stage();
         gather(ipf, cur ^ 1);
@@ -713,8 +762,9 @@ __global__ __launch_bounds__(256, 2) void msg4_rp_kernel(MsgArgsB a) {
             for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
             a.cnt[i] = c;
         }
+        if (tid < TM_TILE) s_ma[cur ^ 1][tid] = nma;
         cur ^= 1;
-        __syncthreads();                                         // tA / tStage consumed, tE complete
+        __syncthreads();                                         // tA / tStage consumed, tE + s_ma[next] complete
     }
 }
 
