@@ -30,7 +30,8 @@ from thermompnn_amd.weights import synthetic_state_dict  # noqa: E402
 
 AA20 = "ACDEFGHIKLMNPQRSTVWY"
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak
+SPLIT_TERMS = {"f16x2": 3, "bf16x3": 6}   # 16-bit MFMAs per fp32-class multiply-accumulate (tmpnn_split.h)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
 
 
@@ -235,7 +236,8 @@ def main():
                                ("; per-step RCCL all-gather of ddG tables" if world > 1 else ""),
                    "proteins_per_gpu": B, "L": L, "K": 48, "h": 128, "preds_per_step": preds_per_step,
                    "weights": "synthetic_state_dict(seed=0)", "parallelism": f"proteins sharded x{world}",
-                   "matmul": lib.tmpnn_matmul_mode().decode() + " (per-edge GEMMs; TMPNN_PRECISION=fp32 selects exact fp32 MFMA)"},
+                   "matmul": lib.tmpnn_matmul_mode().decode() + " (per-edge GEMMs: fp32 operands as split 16-bit planes, fp32 "
+                             "accumulation, fp32-class accuracy; TMPNN_PRECISION=bf16x3|fp32 select the other matrix-core paths)"},
     }
 
     if rank == 0:
@@ -246,15 +248,22 @@ def main():
             fl = kernel_flops(dom, T, edges)
             achieved = fl / (kern[dom]["avg_ms"] * 1e-3) / 1e12
             mode = lib.tmpnn_matmul_mode().decode()
-            split = mode == "bf16x3" and dom in ("enc_edge", "enc_msg", "dec_msg")
-            result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom, T), "kernel": dom,
-                                  "note": ("algorithmic fp32 flops against the fp32 MFMA peak (the problem is an fp32 GEMM chain); "
-                                           "this kernel executes them as six-term bf16x3 split products on the bf16 matrix cores "
-                                           "(see 'executed')" if split else "exact fp32 MFMA"),
-                                  "executed": ({"dtype": "bf16", "flops_per_launch": 6 * fl, "achieved": 6 * achieved,
-                                                "peak": BF16_MFMA_PEAK_TFLOPS, "frac": 6 * achieved / BF16_MFMA_PEAK_TFLOPS}
-                                               if split else None),
+            split_kernels = ("enc_edge", "enc_msg", "dec_msg") + (("featurize",) if mode == "f16x2" else ())
+            terms = SPLIT_TERMS.get(mode, 0) if dom in split_kernels else 0
+            # peak for the ALGORITHMIC (fp32-class) flops: the fp32 matrix pipe, or — on the split paths — the 16-bit
+            # dense peak divided by the MFMAs each multiply-accumulate costs
+            peak = BF16_MFMA_PEAK_TFLOPS / terms if terms else FP32_MFMA_PEAK_TFLOPS
+            result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                                  "frac": achieved / peak, "traffic": pmc_traffic(dom, T), "kernel": dom,
+                                  "note": (f"algorithmic fp32-class flops; the kernel runs them as {terms}-term {mode} split "
+                                           f"products on the 16-bit matrix cores, so peak = {BF16_MFMA_PEAK_TFLOPS:.0f} / {terms} "
+                                           "TFLOP/s ('executed' = the same ratio in executed 16-bit flops; 'vs_fp32_mfma' = "
+                                           "against the fp32 matrix pipe the reference arithmetic would use)"
+                                           if terms else "exact fp32 MFMA"),
+                                  "executed": ({"dtype": "f16" if mode == "f16x2" else "bf16", "flops_per_launch": terms * fl,
+                                                "achieved": terms * achieved, "peak": BF16_MFMA_PEAK_TFLOPS,
+                                                "frac": terms * achieved / BF16_MFMA_PEAK_TFLOPS} if terms else None),
+                                  "vs_fp32_mfma": {"peak": FP32_MFMA_PEAK_TFLOPS, "frac": achieved / FP32_MFMA_PEAK_TFLOPS},
                                   "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_pmc_traffic.json)",
                                   "flops_per_launch": fl, "avg_launch_ms": kern[dom]["avg_ms"],
                                   "timed_with": "hipEvent pairs on the launch stream inside the timed region"}
@@ -267,6 +276,7 @@ def main():
             result["pipeline"] = {"executed_gflop_per_step": total_fl / 1e9,
                                   "tflops_end_to_end": total_fl / (dt / args.steps) / 1e12,
                                   "frac_of_fp32_mfma_peak": total_fl / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                  "note": "algorithmic fp32-class flops of all kernels; > 1 means faster than the fp32 matrix pipe could run them",
                                   "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in kern.values()) / args.steps}
     if rank == 0 and not args.no_extras:
         result["roofline_gather"] = gather_microbench(eng, device)

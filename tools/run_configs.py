@@ -87,7 +87,9 @@ res["config4_megascale_like"] = {"proteins": 300, "residues": b["T"], "mutations
 b = pack([2048], [3])
 dt, k = run(b, 50, 5)
 res["config5_L2048"] = {"ms": dt * 1e3, "preds_per_s": 40960 / dt, "kernel_avg_ms": k,
-                        "lds_bytes_per_workgroup": {"knn (4 rows)": 4 * 2048 * 4, "featurize": 144064, "enc/dec msg": 50048,
-                                                    "enc_edge": 100224, "node_update": 49152, "head": 147648},
-                        "waves_per_simd": {"knn": 8, "featurize": 1, "enc/dec msg": 2, "enc_edge": 1, "node_update": 2, "head": 1}}
+                        # default (f16x2) kernels, from hipcc -Rpass-analysis=kernel-resource-usage
+                        "lds_bytes_per_workgroup": {"knn (4 rows)": 4 * 2048 * 4, "featurize_split": 135232, "msg4 (enc)": 74496,
+                                                    "msg8 (dec)": 76032, "enc_edge8_rp": 77184, "node_update": 49152, "head": 147648},
+                        "waves_per_simd": {"knn": 8, "featurize_split": 2, "msg4 (enc)": 2, "msg8 (dec)": 2, "enc_edge8_rp": 2,
+                                           "node_update": 2, "head": 1}}
 print(json.dumps(res, indent=1))
