@@ -12,7 +12,7 @@
 //   SplitBF3 ("bf16x3"):          x = h + m + l exactly (3 x 8 bits), six partial products hh, hm, mh, hl, lh, mm:
 //            6 MFMAs per step; full fp32 range.
 //
-// Parity (CPU emulation against the reference goldens, every Linear replaced): hidden states 2.6e-6..3.3e-6 (f16x2),
+// Parity (CPU emulation against the reference goldens, every Linear replaced — tests/test_split_precision_sim.py): hidden states 2.6e-6..3.3e-6 (f16x2),
 // 2.0e-6 (bf16x3), 2.2e-6..2.4e-6 for plain fp32 in a different summation order; ddG 3e-6 for all three. A three-term
 // bf16 variant (hh, hm, mh) gives 4e-5 and is NOT used.
 //
