@@ -61,6 +61,16 @@ int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float
 // P [T,256]: P[t, 0:128] = Wa h_t + ba, P[t, 128:256] = Wc h_t (+ add_tab[add_idx[t]] when add_tab is set: the decoder's
 // sequence term W1[:, 256:384] W_s[S_t], which rides with the neighbour's projection)
 struct NodeProj { const float *Wa; int lda; const float *ba; const float *Wc; int ldc; float *P; const float *add_tab; const int32_t *add_idx; };
+// kernel-side argument blocks of node_update (tmpnn_layers.hip: fp32 MFMA; tmpnn_split.hip: f16x2)
+struct ProjSpec { const float *Wa; int lda; const float *ba; const float *Wc; int ldc; float *P; const float *add_tab; const int32_t *add_idx; };
+struct NodeArgs {
+    const float *W3, *b3, *n1w, *n1b, *Win, *bin, *Wout, *bout, *n2w, *n2b;
+    const float *h_in, *Ssum, *cnt, *mask;
+    float *h_out;
+    int T;
+    ProjSpec proj[2];       // proj[k].P == nullptr -> not requested
+};
+int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st);
 int launch_node_proj(const float *h, const NodeProj &np, int64_t T, hipStream_t st);
 int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,

@@ -797,14 +797,6 @@ __global__ __launch_bounds__(TM_THREADS, 1) void enc_edge_pp_kernel(EdgeArgs a) 
 // launches and two re-reads of h per layer. Tile = 16*NRB residues: 48 for batches, 16 when T is small so that a
 // single protein still spreads over more CUs (the weights stream from L2 either way).
 // ------------------------------------------------------------------------------------------------
-struct ProjSpec { const float *Wa; int lda; const float *ba; const float *Wc; int ldc; float *P; const float *add_tab; const int32_t *add_idx; };
-struct NodeArgs {
-    const float *W3, *b3, *n1w, *n1b, *Win, *bin, *Wout, *bout, *n2w, *n2b;
-    const float *h_in, *Ssum, *cnt, *mask;
-    float *h_out;
-    int T;
-    ProjSpec proj[2];       // proj[k].P == nullptr -> not requested
-};
 
 template <int NRB>
 __global__ __launch_bounds__(TM_THREADS, 2) void node_update_kernel(NodeArgs a) {
@@ -1036,6 +1028,12 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
         const int64_t tiles = (T + rows - 1) / rows, rounds = (tiles + slots - 1) / slots;
         const int64_t cost = rounds * (rows + 16);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rows = rows; }
+    }
+    static const bool split_ok = [] { const char *e = getenv("TMPNN_NODE_SPLIT"); return e == nullptr || e[0] != '0'; }();
+    if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
+        const int rc = launch_node_update_split(a, T, st);
+        tm_prof_end(st);
+        return rc;
     }
     const int64_t tiles = (T + best_rows - 1) / best_rows;
     if (best_rows == 16) node_update_kernel<1><<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(a);

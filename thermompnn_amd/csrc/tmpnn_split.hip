@@ -797,3 +797,170 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
     }
     return tm_check_launch(dec ? "dec_msg_split" : "enc_msg_split");
 }
+
+// ------------------------------------------------------------------------------------------------
+// node_update, split-precision form (f16x2): same stages as node_update_kernel (tmpnn_layers.hip) — W3, LN1, FFN
+// 128 -> 512 -> 128 in four chunks, LN2, mask, up to two node projections — with every GEMM on the 16-bit matrix cores.
+// The weights still stream from L2 as fp32 and are split into fragments on the fly (96 VALU per 16 x 128 block: 5 % of a
+// tile's time, against 5x less matrix time); GEMM inputs are plane tiles, LayerNorm inputs fp32 tiles.
+// ------------------------------------------------------------------------------------------------
+template <typename SP, int NRB>
+__global__ __launch_bounds__(TM_THREADS, 2) void node_update_split_kernel(NodeArgs a) {
+    constexpr int ROWS = 16 * NRB, PLT = SP::NP * ROWS * 256;
+    static_assert(PLT >= ROWS * TM_H * 4, "the fp32 LayerNorm-2 input is aliased on the plane tile pA");
+    __shared__ __attribute__((aligned(16))) char pA[PLT];
+    __shared__ __attribute__((aligned(16))) char pB[PLT];
+    __shared__ __attribute__((aligned(16))) float tB[ROWS * TM_H];
+    float *tA = reinterpret_cast<float *>(pA);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int c32 = lane & 31;
+    const int n_tiles = (a.T + ROWS - 1) / ROWS;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int r0 = tile * ROWS;
+        for (int idx = tid; idx < ROWS * 32; idx += TM_THREADS) {          // aggregated messages -> planes
+            const int row = idx >> 5, c = idx & 31;
+            const f4 v = r0 + row < a.T ? ld4(a.Ssum + (size_t)(r0 + row) * TM_H + 4 * c) : f4{0.f, 0.f, 0.f, 0.f};
+            store_split<SP, ROWS>(pA, row, c, v);
+        }
+        __syncthreads();
+
+        WFragS<SP> wf[2][4];
+        f4 acc[NRB][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) load_wfrag_split<SP, 4>(a.W3, TM_H, 32 * wv + 16 * cb, 0, TM_H, wf[cb], lane);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f4{0.f, 0.f, 0.f, 0.f};
+        mma_tile_split<SP, 4, 2, NRB, ROWS>(pA, wf, acc, lane);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const int row = r0 + 16 * rb + m;
+            const bool ok = row < a.T;
+            const float c = ok ? a.cnt[row] : 0.f;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int n = 32 * wv + 16 * cb + 4 * q;
+                const f4 hv = ok ? ld4(a.h_in + (size_t)row * TM_H + n) : f4{0.f, 0.f, 0.f, 0.f};
+                const f4 dh = (acc[rb][cb] + c * ld4(a.b3 + n)) / 30.0f;
+                st4(tB + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), hv + dh);
+            }
+        }
+        __syncthreads();
+        {   // LN1: fp32 in place (the FFN residual) + planes (the FFN input)
+            const f4 g4 = ld4(a.n1w + 4 * c32), b4 = ld4(a.n1b + 4 * c32);
+#pragma unroll
+            for (int it = 0; it < 2 * NRB; ++it) {
+                const int row = 4 * NRB * wv + 2 * it + (lane >> 5);
+                float *p = tB + chunk_off(row, c32);
+                const f4 y = layer_norm_row(ld4(p), g4, b4);
+                st4(p, y);
+                store_split<SP, ROWS>(pB, row, c32, y);
+            }
+        }
+        __syncthreads();
+
+        f4 out[NRB][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const f4 b = ld4(a.bout + 32 * wv + 16 * cb + 4 * q);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) out[rb][cb] = b;
+        }
+        for (int c = 0; c < 4; ++c) {           // FFN hidden 512 in four 128-wide chunks
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int n0 = 128 * c + 32 * wv + 16 * cb;
+                load_wfrag_split<SP, 4>(a.Win, TM_H, n0, 0, TM_H, wf[cb], lane);
+                const f4 b = ld4(a.bin + n0 + 4 * q);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = b;
+            }
+            mma_tile_split<SP, 4, 2, NRB, ROWS>(pB, wf, acc, lane);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    store_split<SP, ROWS>(pA, 16 * rb + m, 8 * wv + 4 * cb + q, gelu4(acc[rb][cb]));
+            __syncthreads();
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) load_wfrag_split<SP, 4>(a.Wout, 512, 32 * wv + 16 * cb, 128 * c, TM_H, wf[cb], lane);
+            mma_tile_split<SP, 4, 2, NRB, ROWS>(pA, wf, out, lane);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int off = chunk_off(16 * rb + m, 8 * wv + 4 * cb + q);
+                st4(tA + off, ld4(tB + off) + out[rb][cb]);                  // tA aliases pA: every wavefront is past its last read
+            }
+        __syncthreads();
+        {   // LN2, mask, coalesced store; the new state goes into the planes pB for the projections
+            const f4 g4 = ld4(a.n2w + 4 * c32), b4 = ld4(a.n2b + 4 * c32);
+#pragma unroll
+            for (int it = 0; it < 2 * NRB; ++it) {
+                const int row = 4 * NRB * wv + 2 * it + (lane >> 5);
+                const int grow = r0 + row;
+                f4 y = layer_norm_row(ld4(tA + chunk_off(row, c32)), g4, b4);
+                y = grow < a.T ? y * a.mask[grow] : f4{0.f, 0.f, 0.f, 0.f};
+                store_split<SP, ROWS>(pB, row, c32, y);
+                if (grow < a.T) st4(a.h_out + (size_t)grow * TM_H + 4 * c32, y);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const ProjSpec &ps = a.proj[k];
+            if (ps.P == nullptr) continue;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int n0 = 32 * wv + 16 * cb;
+                    if (half) load_wfrag_split<SP, 4>(ps.Wc, ps.ldc, n0, 0, TM_H, wf[cb], lane);
+                    else load_wfrag_split<SP, 4>(ps.Wa, ps.lda, n0, 0, TM_H, wf[cb], lane);
+                    const f4 b = half ? f4{0.f, 0.f, 0.f, 0.f} : ld4(ps.ba + n0 + 4 * q);
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = b;
+                }
+                mma_tile_split<SP, 4, 2, NRB, ROWS>(pB, wf, acc, lane);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const int row = r0 + 16 * rb + m;
+                    if (row < a.T) {
+                        const float *add = half && ps.add_tab ? ps.add_tab + ps.add_idx[row] * TM_H : nullptr;
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb) {
+                            const int n = 32 * wv + 16 * cb + 4 * q;
+                            st4(ps.P + (size_t)row * 256 + 128 * half + n, add ? ld4(add + n) + acc[rb][cb] : acc[rb][cb]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
+    // tile height for load balance, as in launch_node_update; the weight stream is worth more rows of (cheaper) matrix time
+    static const int wcost = [] { const char *e = getenv("TMPNN_NODE_WCOST"); return e ? atoi(e) : 48; }();
+    const int64_t slots = (int64_t)2 * tm_num_cus();
+    // (48-row tiles spill 48 VGPRs in this form and still win where they save rounds: 1024 ragged proteins 0.99 vs 1.17 ms)
+    static const int max_rows = [] { const char *e = getenv("TMPNN_NODE_ROWS"); return e ? atoi(e) : 48; }();
+    int best_rows = max_rows;
+    int64_t best_cost = -1;
+    for (int rows = max_rows; rows >= 16; rows -= 16) {
+        const int64_t tiles = (T + rows - 1) / rows, rounds = (tiles + slots - 1) / slots;
+        const int64_t cost = rounds * (rows + wcost);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rows = rows; }
+    }
+    const int64_t tiles = (T + best_rows - 1) / best_rows;
+    const int grid = (int)(tiles < slots ? tiles : slots);
+    if (best_rows == 16) node_update_split_kernel<SplitH2, 1><<<grid, TM_THREADS, 0, st>>>(a);
+    else if (best_rows == 32) node_update_split_kernel<SplitH2, 2><<<grid, TM_THREADS, 0, st>>>(a);
+    else node_update_split_kernel<SplitH2, 3><<<grid, TM_THREADS, 0, st>>>(a);
+    return tm_check_launch("node_update_split");
+}
