@@ -531,6 +531,42 @@ def test_all_matmul_modes_pass_golden_parity(mode):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env", [{"TMPNN_MSG_WAVES": "4"}, {"TMPNN_MSG_WAVES": "8"}, {"TMPNN_SPLIT_DMA": "1"},
+                                 {"TMPNN_NODE_SPLIT": "0", "TMPNN_FEAT_SPLIT": "0"}],
+                         ids=["msg4", "msg8", "dma_staging", "fp32_node_and_featurizer"])
+def test_selectable_kernel_forms_pass_golden_parity(env):
+    """The non-default kernel forms of the f16x2 mode (selected by environment, read once per process) stay parity-green."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import pytest; sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-k', 'fused_forward or ragged_batch', %r]))"
+            % (os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0], os.path.dirname(GOLDEN), __file__))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_f16x2_range_limit_is_loud():
+    """f16x2 needs |x| < 65504: beyond it the GEMM core returns inf/nan (never a silently wrong finite number);
+    bf16x3 and fp32 keep the full fp32 range."""
+    from thermompnn_amd import _lib
+    from thermompnn_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7)
+    X = (torch.randn(4, 48, 128, generator=g) * 1e5).cuda()
+    W = (torch.rand(128, 128, generator=g) * 0.2 - 0.1).cuda()
+    ref = X.double() @ W.double().t()
+    out = {}
+    for mode in (0, 1, 2):
+        Y = torch.zeros_like(X)
+        assert lib.tmpnn_gemm_probe(mode, _ptr(X), _ptr(W), _ptr(Y), 4, 1, _stream()) == 0
+        torch.cuda.synchronize()
+        out[mode] = Y
+    for mode in (0, 1):
+        assert torch.isfinite(out[mode]).all()
+        assert float(((out[mode].double() - ref).abs() / ref.abs().max()).max()) < 1e-5
+    assert not torch.isfinite(out[2]).all()
+
+
 def test_split_precision_gemm_core_accuracy():
     """The split-precision matrix-core GEMMs are in the accuracy class of the exact-fp32 MFMA chain (vs float64)."""
     from thermompnn_amd import _lib
