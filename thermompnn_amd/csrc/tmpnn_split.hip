@@ -944,9 +944,205 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_update_split_kernel(NodeAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// node_update, 8-wavefront f16x2 form (default): one workgroup per CU, up to 64 residues per tile, 16 output columns per
+// wavefront. A tile runs 9..13 dependent GEMMs whose weights stream from L2: the raw fp32 fragment of GEMM u+1 (32 VGPRs)
+// is requested before the MFMAs of GEMM u and split into f16 planes after them, so no GEMM waits on an L2 round trip
+// (the 4-wavefront form above does, 13 times per tile); the taller tile halves the weight traffic per residue.
+// ------------------------------------------------------------------------------------------------
+template <typename SP, int NRB>
+__global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) {
+    constexpr int ROWS = 16 * NRB, PLT = SP::NP * ROWS * 256;
+    static_assert(PLT >= ROWS * TM_H * 4, "the fp32 LayerNorm-2 input is aliased on the plane tile pA");
+    __shared__ __attribute__((aligned(16))) char pA[PLT];
+    __shared__ __attribute__((aligned(16))) char pB[PLT];
+    __shared__ __attribute__((aligned(16))) float tB[ROWS * TM_H];
+    float *tA = reinterpret_cast<float *>(pA);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int c32 = lane & 31, hw = tid >> 5;                  // half-wavefront index: rows hw*NRB .. hw*NRB + NRB - 1
+    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
+    const int n_tiles = (a.T + ROWS - 1) / ROWS;
+    const bool has0 = a.proj[0].P != nullptr, has1 = a.proj[1].P != nullptr;
+
+    // GEMM units of a tile: 0 = W3; 1 + 2c = W_in chunk c, 2 + 2c = W_out chunk c; 9 / 10 = projection 0 (A / C half);
+    // 11 / 12 = projection 1. src(u) = this lane's fragment row: W[(n0 + m) * ld + k0 + 8 q ...]
+    auto src = [&](int u) -> const float * {
+        const size_t r = (size_t)(16 * wv + m);
+        if (u == 0) return a.W3 + r * TM_H + 8 * q;
+        if (u <= 8) {
+            const int c = (u - 1) >> 1;
+            return ((u - 1) & 1) ? a.Wout + r * 512 + 128 * c + 8 * q : a.Win + (r + 128 * c) * TM_H + 8 * q;
+        }
+        const ProjSpec &ps = a.proj[(u - 9) >> 1];
+        return ((u - 9) & 1) ? ps.Wc + r * ps.ldc + 8 * q : ps.Wa + r * ps.lda + 8 * q;
+    };
+    f4 raw[8];
+    auto issue = [&](int u) {
+        const float *p = src(u);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            raw[2 * c] = ld4(p + 32 * c);
+            raw[2 * c + 1] = ld4(p + 32 * c + 4);
+        }
+    };
+    WFragS<SP> wf[1][4];
+    auto split_raw = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned w4[4][SP::NP];
+            SP::split2(f2{raw[2 * c].x, raw[2 * c].y}, w4[0]);
+            SP::split2(f2{raw[2 * c].z, raw[2 * c].w}, w4[1]);
+            SP::split2(f2{raw[2 * c + 1].x, raw[2 * c + 1].y}, w4[2]);
+            SP::split2(f2{raw[2 * c + 1].z, raw[2 * c + 1].w}, w4[3]);
+#pragma unroll
+            for (int p = 0; p < SP::NP; ++p) wf[0][c].p[p] = u4{w4[0][p], w4[1][p], w4[2][p], w4[3][p]};
+        }
+    };
+    const int first_proj = has0 ? 9 : 11;                       // first projection unit, if any
+
+    int tile = blockIdx.x;
+    if (tile < n_tiles) issue(0);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int r0 = tile * ROWS;
+        for (int idx = tid; idx < ROWS * 32; idx += 512) {      // aggregated messages -> planes
+            const int row = idx >> 5, c = idx & 31;
+            const f4 v = r0 + row < a.T ? ld4(a.Ssum + (size_t)(r0 + row) * TM_H + 4 * c) : f4{0.f, 0.f, 0.f, 0.f};
+            store_split<SP, ROWS>(pA, row, c, v);
+        }
+        __syncthreads();
+
+        f4 acc[NRB][1];
+        split_raw();
+        issue(1);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = f4{0.f, 0.f, 0.f, 0.f};
+        mma_tile_split<SP, 4, 1, NRB, ROWS>(pA, wf, acc, lane);
+        {
+            const f4 b3 = ld4(a.b3 + ncol);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const int row = r0 + 16 * rb + m;
+                const bool ok = row < a.T;
+                const float c = ok ? a.cnt[row] : 0.f;
+                const f4 hv = ok ? ld4(a.h_in + (size_t)row * TM_H + ncol) : f4{0.f, 0.f, 0.f, 0.f};
+                const f4 dh = (acc[rb][0] + c * b3) / 30.0f;
+                st4(tB + chunk_off(16 * rb + m, c4), hv + dh);
+            }
+        }
+        __syncthreads();
+        {   // LN1: fp32 in place (the FFN residual) + planes (the FFN input)
+            const f4 g4 = ld4(a.n1w + 4 * c32), b4 = ld4(a.n1b + 4 * c32);
+#pragma unroll
+            for (int it = 0; it < NRB; ++it) {
+                const int row = NRB * hw + it;
+                float *p = tB + chunk_off(row, c32);
+                const f4 y = layer_norm_row(ld4(p), g4, b4);
+                st4(p, y);
+                store_split<SP, ROWS>(pB, row, c32, y);
+            }
+        }
+        __syncthreads();
+
+        f4 out[NRB][1];
+        {
+            const f4 b = ld4(a.bout + ncol);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) out[rb][0] = b;
+        }
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {           // FFN hidden 512 in four 128-wide chunks
+            split_raw();                        // W_in chunk c
+            issue(2 + 2 * c);
+            {
+                const f4 b = ld4(a.bin + 128 * c + ncol);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
+            }
+            mma_tile_split<SP, 4, 1, NRB, ROWS>(pB, wf, acc, lane);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) store_split<SP, ROWS>(pA, 16 * rb + m, c4, gelu4(acc[rb][0]));
+            __syncthreads();
+            split_raw();                        // W_out chunk c
+            if (c < 3) issue(3 + 2 * c);
+            else if (has0 || has1) issue(first_proj);
+            else if (tile + (int)gridDim.x < n_tiles) issue(0);
+            mma_tile_split<SP, 4, 1, NRB, ROWS>(pA, wf, out, lane);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const int off = chunk_off(16 * rb + m, c4);
+            st4(tA + off, ld4(tB + off) + out[rb][0]);                       // tA aliases pA: every wavefront is past its last read
+        }
+        __syncthreads();
+        {   // LN2, mask, coalesced store; the new state goes into the planes pB for the projections
+            const f4 g4 = ld4(a.n2w + 4 * c32), b4 = ld4(a.n2b + 4 * c32);
+#pragma unroll
+            for (int it = 0; it < NRB; ++it) {
+                const int row = NRB * hw + it;
+                const int grow = r0 + row;
+                f4 y = layer_norm_row(ld4(tA + chunk_off(row, c32)), g4, b4);
+                y = grow < a.T ? y * a.mask[grow] : f4{0.f, 0.f, 0.f, 0.f};
+                store_split<SP, ROWS>(pB, row, c32, y);
+                if (grow < a.T) st4(a.h_out + (size_t)grow * TM_H + 4 * c32, y);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const ProjSpec &ps = a.proj[k];
+            if (ps.P == nullptr) continue;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                split_raw();
+                // next unit: the C half, the other projection, or W3 of this workgroup's next tile
+                if (!half) issue(10 + 2 * k);
+                else if (k == 0 && has1) issue(11);
+                else if (tile + (int)gridDim.x < n_tiles) issue(0);
+                {
+                    const f4 b = half ? f4{0.f, 0.f, 0.f, 0.f} : ld4(ps.ba + ncol);
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
+                }
+                mma_tile_split<SP, 4, 1, NRB, ROWS>(pB, wf, acc, lane);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const int row = r0 + 16 * rb + m;
+                    if (row < a.T) {
+                        const float *add = half && ps.add_tab ? ps.add_tab + ps.add_idx[row] * TM_H : nullptr;
+                        st4(ps.P + (size_t)row * 256 + 128 * half + ncol, add ? ld4(add + ncol) + acc[rb][0] : acc[rb][0]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
     // tile height for load balance, as in launch_node_update; the weight stream is worth more rows of (cheaper) matrix time
     static const int wcost = [] { const char *e = getenv("TMPNN_NODE_WCOST"); return e ? atoi(e) : 48; }();
+    static const int waves = [] { const char *e = getenv("TMPNN_NODE_WAVES"); return e ? atoi(e) : 8; }();
+    if (waves == 8) {                            // 8-wavefront form: one workgroup per CU, 16..64 rows per tile
+        const int64_t slots = tm_num_cus();
+        static const int max_rows8 = [] { const char *e = getenv("TMPNN_NODE_ROWS"); return e ? atoi(e) : 64; }();
+        int best_rows = max_rows8;
+        int64_t best_cost = -1;
+        for (int rows = max_rows8; rows >= 16; rows -= 16) {
+            const int64_t tiles = (T + rows - 1) / rows, rounds = (tiles + slots - 1) / slots;
+            const int64_t cost = rounds * (rows + wcost);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rows = rows; }
+        }
+        const int64_t tiles = (T + best_rows - 1) / best_rows;
+        const int grid = (int)(tiles < slots ? tiles : slots);
+        switch (best_rows) {
+            case 16: node_update8_split_kernel<SplitH2, 1><<<grid, 512, 0, st>>>(a); break;
+            case 32: node_update8_split_kernel<SplitH2, 2><<<grid, 512, 0, st>>>(a); break;
+            case 48: node_update8_split_kernel<SplitH2, 3><<<grid, 512, 0, st>>>(a); break;
+            default: node_update8_split_kernel<SplitH2, 4><<<grid, 512, 0, st>>>(a); break;
+        }
+        return tm_check_launch("node_update8_split");
+    }
     const int64_t slots = (int64_t)2 * tm_num_cus();
     // (48-row tiles spill 48 VGPRs in this form and still win where they save rounds: 1024 ragged proteins 0.99 vs 1.17 ms)
     static const int max_rows = [] { const char *e = getenv("TMPNN_NODE_ROWS"); return e ? atoi(e) : 48; }();
