@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
                 const float *A = s_self + 3 * c_pair_a[p];
                 const float *B = s_atoms[mm] + 3 * c_pair_b[p];
                 const float dx = A[0] - B[0], dy = A[1] - B[1], dz = A[2] - B[2];
-                D = sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);  // _get_rbf (:1122)
+                D = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);  // _get_rbf (:1122); v_sqrt_f32, 1 ulp
             }
             s_dist[mm][p] = D;
         }
@@ -380,15 +380,12 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
         for (int e = tid; e < TM_TILE * 100; e += 512) {        // 16 Gaussians per pair, 4 per thread (:1111-1119)
             const int mm = e / 100, c = e - mm * 100;
             const float D = s_dist[mm][c >> 2];
-            f4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float t = (D - mu4[r]) * 0.8f;            // / sigma, sigma = 1.25
-                v[r] = __expf(-(t * t));
-            }
+            // exp(-((D - mu) / 1.25)^2) = exp2(-(t t)), t = (D - mu) * 0.8 sqrt(log2 e): packed fp32, two centres per op
+            const f2 t01 = (f2{D, D} - f2{mu4.x, mu4.y}) * 0.96089795f, t23 = (f2{D, D} - f2{mu4.z, mu4.w}) * 0.96089795f;
+            const f2 e01 = -(t01 * t01), e23 = -(t23 * t23);
             unsigned lo2[SP::NP], hi2[SP::NP];
-            SP::split2(f2{v.x, v.y}, lo2);
-            SP::split2(f2{v.z, v.w}, hi2);
+            SP::split2(f2{__builtin_amdgcn_exp2f(e01.x), __builtin_amdgcn_exp2f(e01.y)}, lo2);
+            SP::split2(f2{__builtin_amdgcn_exp2f(e23.x), __builtin_amdgcn_exp2f(e23.y)}, hi2);
 #pragma unroll
             for (int p = 0; p < SP::NP; ++p)
                 *reinterpret_cast<u2 *>(rbf + plane_off4<TM_TILE, RBFP_ROWB>(p, mm, c)) = u2{lo2[p], hi2[p]};
