@@ -351,8 +351,12 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
             if (p == 0) {
                 D = s_atoms[mm][15];
             } else {
-                const float *A = s_self + 3 * c_pair_a[p];
-                const float *B = s_atoms[mm] + 3 * c_pair_b[p];
+                // atom indices of pair p (c_pair_a / c_pair_b, 3 bits each) from immediates: no per-lane constant-memory load
+                const int sh = 3 * (p & 15);
+                const int ia = (int)(((p < 16 ? 0xe400124c681ull : 0x26a351aull) >> sh) & 7ull);
+                const int ib = (int)(((p < 16 ? 0x29a8d4684681ull : 0x3900049ull) >> sh) & 7ull);
+                const float *A = s_self + 3 * ia;
+                const float *B = s_atoms[mm] + 3 * ib;
                 const float dx = A[0] - B[0], dy = A[1] - B[1], dz = A[2] - B[2];
                 D = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);  // _get_rbf (:1122); v_sqrt_f32, 1 ulp
             }
