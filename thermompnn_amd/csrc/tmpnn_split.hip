@@ -280,10 +280,13 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
         mma_tile_split<SP, 4, 1>(tE, w11, acc, lane);
         mark(0);
+        {   // the three row blocks' GELUs as six independent chains, then the three splits
+            f4 g[3];
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            store_split<SP>(tX, 16 * rb + m, c4, gelu4(acc[rb][0]));
-            __builtin_amdgcn_sched_barrier(0);      // one row block at a time: keeps the GELU temporaries out of the weight VGPRs
+            for (int rb = 0; rb < 3; ++rb) g[rb] = gelu4(acc[rb][0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) store_split<SP>(tX, 16 * rb + m, c4, g[rb]);
         }
         if (tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx;
         mark(1);
@@ -300,10 +303,13 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
         mma_tile_split<SP, 4, 1>(tX, w12, acc, lane);
         mark(3);
+        {
+            f4 g[3];
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            store_split<SP>(tY, 16 * rb + m, c4, gelu4(acc[rb][0]));
+            for (int rb = 0; rb < 3; ++rb) g[rb] = gelu4(acc[rb][0]);
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) store_split<SP>(tY, 16 * rb + m, c4, g[rb]);
         }
         mark(4);
         __syncthreads();
