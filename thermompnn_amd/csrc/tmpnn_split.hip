@@ -5,6 +5,16 @@
 #include <type_traits>
 
 #include "tmpnn_split.h"
+
+#ifndef TM_EDGE_PF
+#define TM_EDGE_PF 0     // the same for the edge-update kernel (measured: its three 12-step GEMMs gain nothing, 0.379 vs 0.386 ms)
+#endif
+#ifndef TM_NODE_PF
+#define TM_NODE_PF 3
+#endif
+#ifndef TM_MSG_PF
+#define TM_MSG_PF 3      // B-fragment prefetch distance (steps) of the 8-wavefront message kernel GEMMs, see mma_tile_split
+#endif
 #include "tmpnn_internal.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
-        mma_tile_split<SP, 4, 1>(tE, w11, acc, lane);
+        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tE, w11, acc, lane);
         mark(0);
         {   // the three row blocks' GELUs as six independent chains, then the three splits
             f4 g[3];
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         }
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
-        mma_tile_split<SP, 4, 1>(tX, w12, acc, lane);
+        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tX, w12, acc, lane);
         mark(3);
         {
             f4 g[3];
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
 
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
-        mma_tile_split<SP, 4, 1>(tY, w13, acc, lane);
+        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tY, w13, acc, lane);
         mark(6);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
@@ -513,8 +523,16 @@ __global__ __launch_bounds__(512, 2) void msg8_split_kernel(MsgArgsB a) {
 
 // Register-prefetch form of the message kernel (f16x2): the next residue's fp32 tile is loaded in the accumulator
 // layout at the top of the iteration and split into the e planes once GEMM 1 has consumed the current ones.
-template <typename SP, bool DEC>
-__global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
+template <typename SP, bool DEC, bool PROF = false>
+__global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned long long *prof = nullptr) {
+    unsigned long long t_last = 0;
+    auto mark = [&](int k) {           // TMPNN_MSG_PROF=1: phase timing of thread 0 of workgroup 0
+        if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            if (k >= 0) prof[k] += t - t_last;
+            t_last = t;
+        }
+    };
     constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
     __shared__ __attribute__((aligned(16))) char tE[TILEB];
     __shared__ __attribute__((aligned(16))) char tA[TILEB];
@@ -571,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
         gather(i, 0);
         __syncthreads();
     }
+    mark(-1);
     for (; i < tr.end; i += tr.step) {
         const int inext = i + tr.step;
         const int ipf = inext < tr.end ? inext : i;             // the last iteration prefetches its own tile again
@@ -583,7 +602,8 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
-        mma_tile_split<SP, 4, 1>(tE, w1, acc, lane);
+        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tE, w1, acc, lane);
+        mark(0);
         float nma = 0.f;
         if (tid < TM_TILE && nidx >= 0) nma = DEC ? 1.f : a.mask[ipf] * a.mask[nidx];
 #pragma unroll
@@ -596,13 +616,17 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
             s_idx[cur ^ 1][tid] = nidx;
             s_ma[cur ^ 1][tid] = nma;
         }
+        mark(1);
         __syncthreads();                                         // tE consumed; tA, s_idx/s_ma[next] complete
+        mark(2);
 
         split_tile();
         gather(ipf, cur ^ 1);
+        mark(3);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = bias2;
-        mma_tile_split<SP, 4, 1>(tA, w2, acc, lane);
+        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tA, w2, acc, lane);
+        mark(4);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             const float ma = s_ma[cur][16 * rb + m];
@@ -615,7 +639,9 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
             for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
             a.cnt[i] = c;
         }
+        mark(5);
         __syncthreads();
+        mark(6);
         {   // per-node aggregation: column sums over 4 row groups of 12, combined in a fixed order
             const int n = tid & 127, grp = tid >> 7;
             float s = 0.f;
@@ -626,6 +652,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a) {
             if (!grp) a.Ssum[(size_t)i * TM_H + n] = ((s + s_part[0][n]) + s_part[1][n]) + s_part[2][n];
         }
         cur ^= 1;
+        mark(7);
         // no barrier here (see msg8_split_kernel)
     }
 }
@@ -785,15 +812,25 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
         else msg8_split_kernel<SplitBF3, false><<<grid, 512, 0, st>>>(a);
     } else {
         static const bool dma = [] { const char *e = getenv("TMPNN_SPLIT_DMA"); return e != nullptr && e[0] == '1'; }();
-        // measured on MI355X (same run, 64 x L=256): encoder 4-wavefront form 0.252 vs 0.256 ms, decoder 8-wavefront
-        // form 0.248 vs 0.260 ms -> each layer type gets its faster form unless TMPNN_MSG_WAVES pins one
+        // measured on MI355X (same run, 64 x L=256): with its B-fragment reads pipelined (TM_MSG_PF) the 8-wavefront form
+        // runs 0.238 (enc) / 0.235 ms (dec) against 0.252 / 0.260 ms for the 4-wavefront form (TMPNN_MSG_WAVES=4)
         static const int nw_env = [] { const char *e = getenv("TMPNN_MSG_WAVES"); return e ? atoi(e) : 0; }();
-        const int nw = nw_env ? nw_env : (dec ? 8 : 4);
+        const int nw = nw_env ? nw_env : 8;
         if (dma) {
             if (dec) msg8_split_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
             else msg8_split_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
         } else if (nw == 8) {
-            if (dec) msg8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
+            static const bool prof = [] { const char *e = getenv("TMPNN_MSG_PROF"); return e != nullptr && e[0] == '1'; }();
+            if (prof && dec) {                       // debug: phase timing of workgroup 0 (synchronises!)
+                static unsigned long long *d_prof = nullptr;
+                if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
+                (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+                msg8_rp_kernel<SplitH2, true, true><<<grid, 512, 0, st>>>(a, d_prof);
+                unsigned long long h[16];
+                (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+                fprintf(stderr, "dec_msg phases (cycles, wg 0): fetch+gemm1 %llu gelu+split %llu bar %llu split_tile+gather %llu gemm2 %llu gelu+mask %llu bar %llu ksum+store %llu\n",
+                        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+            } else if (dec) msg8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
             else msg8_rp_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
         } else {
             const int grid2 = (int)(T < 2 * cap ? T : 2 * cap);
@@ -1022,7 +1059,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
         issue(1);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = f4{0.f, 0.f, 0.f, 0.f};
-        mma_tile_split<SP, 4, 1, NRB, ROWS>(pA, wf, acc, lane);
+        mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pA, wf, acc, lane);
         {
             const f4 b3 = ld4(a.b3 + ncol);
 #pragma unroll
@@ -1064,7 +1101,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
             }
-            mma_tile_split<SP, 4, 1, NRB, ROWS>(pB, wf, acc, lane);
+            mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pB, wf, acc, lane);
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) store_split<SP, ROWS>(pA, 16 * rb + m, c4, gelu4(acc[rb][0]));
             __syncthreads();
@@ -1072,7 +1109,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
             if (c < 3) issue(3 + 2 * c);
             else if (has0 || has1) issue(first_proj);
             else if (tile + (int)gridDim.x < n_tiles) issue(0);
-            mma_tile_split<SP, 4, 1, NRB, ROWS>(pA, wf, out, lane);
+            mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pA, wf, out, lane);
             __syncthreads();
         }
 #pragma unroll
@@ -1110,7 +1147,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
                 }
-                mma_tile_split<SP, 4, 1, NRB, ROWS>(pB, wf, acc, lane);
+                mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pB, wf, acc, lane);
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     const int row = r0 + 16 * rb + m;
