@@ -12,6 +12,9 @@
 #ifndef TM_NODE_PF
 #define TM_NODE_PF 3
 #endif
+#ifndef TM_MSG_TOUCH
+#define TM_MSG_TOUCH 1
+#endif
 #ifndef TM_MSG_PF
 #define TM_MSG_PF 3      // B-fragment prefetch distance (steps) of the 8-wavefront message kernel GEMMs, see mma_tile_split
 #endif
@@ -586,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         fetch_tile(i);
         __syncthreads();
         split_tile();
+        fetch_tile(i + tr.step < tr.end ? i + tr.step : i);     // e_nxt always holds the tile AFTER the one in the planes
         gather(i, 0);
         __syncthreads();
     }
@@ -598,7 +602,6 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         // published to LDS only after the epilogue — no wavefront ever sits on a global-load latency in front of its MFMAs
         int nidx = -1;
         if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf * TM_KS + tid];
-        fetch_tile(ipf);
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
@@ -621,6 +624,9 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         mark(2);
 
         split_tile();
+        // the tile after the next is requested now and consumed one full iteration later (an HBM round trip under load
+        // is longer than the GEMM 1 + GELU phase the request used to be given)
+        fetch_tile(ipf + tr.step < tr.end ? ipf + tr.step : ipf);
         gather(ipf, cur ^ 1);
         mark(3);
 #pragma unroll
@@ -633,6 +639,11 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
             f4 v = gelu4(acc[rb][0]) * ma;
             if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
             st4(tS + chunk_off(16 * rb + m, c4), v);
+        }
+        if (TM_MSG_TOUCH) {                                      // take the gathers' vmcnt wait before any store is issued (see touch())
+            touch(g0);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) touch(gj[rb]);
         }
         if (tid == 128) {                                        // neighbour count of this tile (read before s_ma[cur] is recycled)
             float c = 0.f;
