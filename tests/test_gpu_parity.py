@@ -532,8 +532,8 @@ def test_all_matmul_modes_pass_golden_parity(mode):
 
 
 @pytest.mark.parametrize("env", [{"TMPNN_MSG_WAVES": "4"}, {"TMPNN_MSG_WAVES": "8"}, {"TMPNN_SPLIT_DMA": "1"},
-                                 {"TMPNN_NODE_SPLIT": "0", "TMPNN_FEAT_SPLIT": "0"}],
-                         ids=["msg4", "msg8", "dma_staging", "fp32_node_and_featurizer"])
+                                 {"TMPNN_NODE_SPLIT": "0", "TMPNN_FEAT_SPLIT": "0", "TMPNN_HEAD_SPLIT": "0"}, {"TMPNN_NODE_WAVES": "4"}],
+                         ids=["msg4", "msg8", "dma_staging", "fp32_node_featurizer_head", "node4"])
 def test_selectable_kernel_forms_pass_golden_parity(env):
     """The non-default kernel forms of the f16x2 mode (selected by environment, read once per process) stay parity-green."""
     import subprocess

@@ -5,8 +5,11 @@
 // tap of feature_convolution (softmax over a size-1 axis is 1, dropout is identity in eval);
 // both_out = [ReLU, Linear] x3 (:67-71); ddg_out = Linear(1,1) (:73); W_out + log_softmax
 // (protein_mpnn_utils.py:1275-1276); W_s embedding (:1238).
+#include <stdlib.h>
+
 #include "tmpnn_common.h"
 #include "tmpnn_internal.h"
+#include "tmpnn_split.h"
 
 struct HeadArgs {
     const float *conv_center, *conv_b;   // [384,384], [384]
@@ -123,6 +126,148 @@ __global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// head, 8-wavefront f16x2 form (default in f16x2 mode): the 384 -> 384 centre-tap GEMM and the 384 -> 64 layer (12 GEMM
+// units of K = 128) on the 16-bit matrix cores, 16 output columns per wavefront, the fp32 weight fragment of unit u+1
+// fetched from L2 under the MFMAs of unit u (as in node_update8_split_kernel); the two tiny layers (64 -> 32 -> 21) and
+// the ddG epilogue are the fp32 code of head_kernel.
+// ------------------------------------------------------------------------------------------------
+template <typename SP, int NRB>
+__global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
+    constexpr int ROWS = 16 * NRB, PLT = SP::NP * ROWS * 256;
+    static_assert(PLT >= ROWS * TM_H * 4, "fp32 tiles of the small layers are aliased on dead x planes");
+    __shared__ __attribute__((aligned(16))) char pX[3][PLT];
+    __shared__ __attribute__((aligned(16))) char pY[3][PLT];
+    __shared__ int s_S[ROWS];
+    float *tF0 = reinterpret_cast<float *>(pX[0]), *tF1 = reinterpret_cast<float *>(pX[1]), *tF2 = reinterpret_cast<float *>(pX[2]);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
+    const int n_tiles = (a.T + ROWS - 1) / ROWS;
+    const float dw = a.ddg_w[0], db = a.ddg_b[0];
+
+    // units 0..8: conv_center rows 128 g + 16 wv + m, columns 128 kt (u = 3 g + kt); units 9..11: w1 rows 16 wv + m (wv < 4)
+    auto src = [&](int u) -> const float * {
+        if (u < 9) return a.conv_center + (size_t)(128 * (u / 3) + 16 * wv + m) * 384 + 128 * (u % 3) + 8 * q;
+        return a.w1 + (size_t)(16 * (wv & 3) + m) * 384 + 128 * (u - 9) + 8 * q;
+    };
+    f4 raw[8];
+    auto issue = [&](int u) {
+        const float *p = src(u);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            raw[2 * c] = ld4(p + 32 * c);
+            raw[2 * c + 1] = ld4(p + 32 * c + 4);
+        }
+    };
+    WFragS<SP> wf[1][4];
+    auto split_raw = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned w4[4][SP::NP];
+            SP::split2(f2{raw[2 * c].x, raw[2 * c].y}, w4[0]);
+            SP::split2(f2{raw[2 * c].z, raw[2 * c].w}, w4[1]);
+            SP::split2(f2{raw[2 * c + 1].x, raw[2 * c + 1].y}, w4[2]);
+            SP::split2(f2{raw[2 * c + 1].z, raw[2 * c + 1].w}, w4[3]);
+#pragma unroll
+            for (int p = 0; p < SP::NP; ++p) wf[0][c].p[p] = u4{w4[0][p], w4[1][p], w4[2][p], w4[3][p]};
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < n_tiles) issue(0);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int r0 = tile * ROWS, rows = min(ROWS, a.T - r0);
+        if (tid < ROWS) s_S[tid] = tid < rows ? a.S[r0 + tid] : 0;
+        for (int idx = tid; idx < ROWS * 32; idx += 512) {      // x = [h_last | h_prev | W_s[S]] -> planes
+            const int row = idx >> 5, c = idx & 31;
+            const bool ok = row < rows;
+            const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+            store_split<SP, ROWS>(pX[0], row, c, ok ? ld4(a.hA + (size_t)(r0 + row) * TM_H + 4 * c) : z);
+            store_split<SP, ROWS>(pX[1], row, c, ok ? ld4(a.hB + (size_t)(r0 + row) * TM_H + 4 * c) : z);
+            store_split<SP, ROWS>(pX[2], row, c, ld4(a.Ws + (ok ? a.S[r0 + row] : 0) * TM_H + 4 * c));
+        }
+        __syncthreads();
+
+        // y = relu(Wc x + bc), 384 -> 384 in three 128-column groups
+#pragma unroll 1
+        for (int g = 0; g < 3; ++g) {
+            f4 acc[NRB][1];
+            {
+                const f4 b = ld4(a.conv_b + 128 * g + ncol);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
+            }
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                split_raw();
+                const int un = 3 * g + kt + 1;                  // next unit; 9..11 only exist for wavefronts 0..3
+                if (un < 9 || wv < 4) issue(un);
+                mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, 3>(pX[kt], wf, acc, lane);
+            }
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) store_split<SP, ROWS>(pY[g], 16 * rb + m, c4, relu4(acc[rb][0]));
+        }
+        __syncthreads();
+
+        if (wv < 4) {   // 384 -> 64, relu; wavefront w owns columns 16w..16w+15 -> tF0[:, 0:64] (x planes are dead)
+            f4 acc[NRB][1];
+            {
+                const f4 b = ld4(a.b1 + ncol);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
+            }
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                split_raw();
+                if (kt < 2) issue(10 + kt);
+                mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, 3>(pY[kt], wf, acc, lane);
+            }
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) st4(tF0 + chunk_off(16 * rb + m, c4), relu4(acc[rb][0]));
+        }
+        if (tile + (int)gridDim.x < n_tiles) issue(0);          // unit 0 of this workgroup's next tile
+        __syncthreads();
+        if (wv < 2) {   // 64 -> 32, relu -> tF1[:, 0:32]
+            f4 acc[NRB][1];
+            const f4 b = ld4(a.b2 + ncol);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
+            float w32[1][16];
+            load_wfrag<4>(a.w2, 64, 16 * wv, 0, 32, w32[0], lane);
+            mma_tile<4, 1, 128, NRB>(tF0, w32, acc, lane);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) st4(tF1 + chunk_off(16 * rb + m, c4), relu4(acc[rb][0]));
+        }
+        __syncthreads();
+        if (wv < 2) {   // 32 -> 21 (rows 21..31 of the weight read as zero) -> z in tF2[:, 0:32]
+            f4 acc[NRB][1];
+            f4 b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = ncol + r;
+                b[r] = n < TMPNN_VOCAB ? a.b3[n] : 0.f;
+            }
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
+            float w8[1][8];
+            load_wfrag<2>(a.w3, 32, 16 * wv, 0, TMPNN_VOCAB, w8[0], lane);
+            mma_tile<2, 1, 128, NRB>(tF1, w8, acc, lane);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) st4(tF2 + chunk_off(16 * rb + m, c4), acc[rb][0]);
+        }
+        __syncthreads();
+        for (int e = tid; e < rows * TMPNN_VOCAB; e += 512) {
+            const int row = e / TMPNN_VOCAB, aa = e - row * TMPNN_VOCAB;
+            const float z = tF2[chunk_off(row, aa >> 2) + (aa & 3)];
+            const int wt = s_S[row];
+            const float zw = tF2[chunk_off(row, wt >> 2) + (wt & 3)];
+            a.ddg[(size_t)(r0 + row) * TMPNN_VOCAB + aa] = (dw * z + db) - (dw * zw + db);   // :110-116
+            if (a.z_opt) a.z_opt[(size_t)(r0 + row) * TMPNN_VOCAB + aa] = z;
+        }
+        __syncthreads();
+    }
+}
+
 // log_softmax(W_out h + b): one wavefront per residue, lane a < 21 owns logit a.
 __global__ __launch_bounds__(TM_THREADS) void log_probs_kernel(const float *__restrict__ W, const float *__restrict__ b,
                                                                const float *__restrict__ h, int T,
@@ -202,6 +347,14 @@ int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const 
     const int64_t tiles = (T + best_rows - 1) / best_rows;
     const int grid = (int)(tiles < slots ? tiles : slots);
     tm_prof_begin("head", st);
+    static const bool split_ok = [] { const char *e = getenv("TMPNN_HEAD_SPLIT"); return e == nullptr || e[0] != '0'; }();
+    if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
+        if (best_rows == 16) head8_split_kernel<SplitH2, 1><<<grid, 512, 0, st>>>(a);
+        else if (best_rows == 32) head8_split_kernel<SplitH2, 2><<<grid, 512, 0, st>>>(a);
+        else head8_split_kernel<SplitH2, 3><<<grid, 512, 0, st>>>(a);
+        tm_prof_end(st);
+        return tm_check_launch("ddg_head");
+    }
     if (best_rows == 16) head_kernel<1><<<grid, TM_THREADS, 0, st>>>(a);
     else if (best_rows == 32) head_kernel<2><<<grid, TM_THREADS, 0, st>>>(a);
     else head_kernel<3><<<grid, TM_THREADS, 0, st>>>(a);
