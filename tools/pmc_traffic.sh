@@ -11,8 +11,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python - <<PY
 import csv, glob, json, collections
-LOGICAL = [("enc_edge", "enc_edge"), ("msg4_rp_kernel<SplitH2, false>", "enc_msg"), ("msg8_rp_kernel<SplitH2, false>", "enc_msg"),
-           ("msg4_rp_kernel<SplitH2, true>", "dec_msg"), ("msg8_rp_kernel<SplitH2, true>", "dec_msg"), ("featurize", "featurize"),
+LOGICAL = [("enc_edge", "enc_edge"), ("msg4_rp_kernel<SplitH2, false", "enc_msg"), ("msg8_rp_kernel<SplitH2, false", "enc_msg"),
+           ("msg4_rp_kernel<SplitH2, true", "dec_msg"), ("msg8_rp_kernel<SplitH2, true", "dec_msg"), ("featurize", "featurize"),
            ("gather_rows_kernel", "gather_rows"), ("copyBuffer", "device_copy_calibration"), ("node_update", "node_update"),
            ("knn_kernel", "knn"), ("head_kernel", "head"), ("node_proj", "node_proj")]
 T, E = 16384, 16384 * 48
