@@ -82,6 +82,8 @@ __global__ __launch_bounds__(TM_THREADS) void knn_kernel(const float *__restrict
             if (bits < best_d) { best_d = bits; best_j = (unsigned)j; }
         }
         wave_lds_fence();
+        int out_j = -1;                                          // lane t keeps the t-th neighbour: one coalesced store per row
+        float out_d = 0.f;
         for (int t = 0; t < Keff; ++t) {
             const unsigned g = wave_min_u32(best_d);
             const unsigned long long tied = __ballot(best_d == g);
@@ -91,9 +93,9 @@ __global__ __launch_bounds__(TM_THREADS) void knn_kernel(const float *__restrict
             } else {                                             // exact tie between lanes: lowest index wins
                 j = wave_min_u32(best_d == g ? best_j : 0xffffffffu);
             }
-            if (lane == 0) {
-                E_idx[(size_t)i * TM_KS + t] = s + (int)j;
-                D_nb[(size_t)i * TM_KS + t] = __uint_as_float(g);
+            if (lane == t) {
+                out_j = s + (int)j;
+                out_d = __uint_as_float(g);
             }
             if ((j & 63u) == (unsigned)lane) {                   // owner lane retires j and rescans its stripe
                 d[j] = __uint_as_float(0x7f800000u);
@@ -106,9 +108,9 @@ __global__ __launch_bounds__(TM_THREADS) void knn_kernel(const float *__restrict
                 }
             }
         }
-        for (int t = Keff + lane; t < TM_KS; t += 64) {
-            E_idx[(size_t)i * TM_KS + t] = -1;
-            D_nb[(size_t)i * TM_KS + t] = 0.f;
+        if (lane < TM_KS) {                                      // slots >= Keff keep (-1, 0)
+            E_idx[(size_t)i * TM_KS + lane] = out_j;
+            D_nb[(size_t)i * TM_KS + lane] = out_d;
         }
         wave_lds_fence();
     }
