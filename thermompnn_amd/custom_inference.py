@@ -68,7 +68,11 @@ def ssm_rows(model, pdb_path: str, chain: str, model_name: str = "ThermoMPNN"):
     muts = mutation_objects(mut_pdb[0])
     with torch.no_grad():
         pred, _ = model(mut_pdb, muts)
-    vals = torch.cat([p["ddG"] for p in pred if p is not None]).cpu().tolist()     # one D2H copy
+    vals = torch.cat([p["ddG"] for p in pred if p is not None]).cpu()              # one D2H copy
+    if not bool(torch.isfinite(vals).all()):
+        raise RuntimeError("non-finite ddG: the default f16x2 matrix-core path needs |activations| < 65504 — "
+                           "rerun with TMPNN_PRECISION=bf16x3 (full fp32 range)")
+    vals = vals.tolist()
     rows, k = [], 0
     dataset = pdb_id_of(pdb_path)
     for m in muts:

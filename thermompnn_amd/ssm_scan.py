@@ -52,6 +52,9 @@ def scan_proteins(engine, proteins: Sequence[dict], centrality: bool = False, ch
         ddg = engine.ssm_forward(b["X"], b["S"], b["mask"], b["ridx"], b["cenc"], b["offsets"], max_len=b["max_len"])["ddg"]
         cen = engine.centrality(b["X"], b["mask"], b["offsets"], 10.0).cpu().numpy() if centrality else None
         ddg = ddg.cpu().numpy()                                  # one D2H copy per chunk
+        if not np.isfinite(ddg[:, :20]).all():
+            raise RuntimeError("non-finite ddG: the default f16x2 matrix-core path needs |activations| < 65504 — "
+                               "rerun with TMPNN_PRECISION=bf16x3 (full fp32 range)")
         pos = 0
         for pid in ids:
             L = len(proteins[pid]["S"])
