@@ -539,8 +539,6 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
     __shared__ __attribute__((aligned(16))) char tE[TILEB];
     __shared__ __attribute__((aligned(16))) char tA[TILEB];
-    __shared__ __attribute__((aligned(16))) float tS[TM_TILE * TM_H];
-    __shared__ float s_part[3][TM_H];
     __shared__ int s_idx[2][TM_TILE];
     __shared__ float s_ma[2][TM_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
@@ -633,38 +631,39 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = bias2;
         mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tA, w2, acc, lane);
         mark(4);
+        f4 tot = f4{0.f, 0.f, 0.f, 0.f};                         // masked sum over the K neighbours, in registers
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             const float ma = s_ma[cur][16 * rb + m];
             f4 v = gelu4(acc[rb][0]) * ma;
             if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
-            st4(tS + chunk_off(16 * rb + m, c4), v);
+            tot += v;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                             // inclusive scan over the 16 rows of the lane group (DPP row_shr,
+            float x = tot[c];                                    // zero fill): lane m = 15 ends up with the column sum
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xf, 0xf, true));
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, true));
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xf, 0xf, true));
+            tot[c] = x;
         }
         if (TM_MSG_TOUCH) {                                      // take the gathers' vmcnt wait before any store is issued (see touch())
             touch(g0);
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) touch(gj[rb]);
         }
+        if (m == 15) st4(a.Ssum + (size_t)i * TM_H + ncol, tot);
         if (tid == 128) {                                        // neighbour count of this tile (read before s_ma[cur] is recycled)
             float c = 0.f;
             for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
             a.cnt[i] = c;
         }
         mark(5);
-        __syncthreads();
         mark(6);
-        {   // per-node aggregation: column sums over 4 row groups of 12, combined in a fixed order
-            const int n = tid & 127, grp = tid >> 7;
-            float s = 0.f;
-#pragma unroll
-            for (int r = 12 * grp; r < 12 * grp + 12; ++r) s += tS[chunk_off(r, n >> 2) + (n & 3)];
-            if (grp) s_part[grp - 1][n] = s;
-            __syncthreads();
-            if (!grp) a.Ssum[(size_t)i * TM_H + n] = ((s + s_part[0][n]) + s_part[1][n]) + s_part[2][n];
-        }
         cur ^= 1;
+        __syncthreads();                                         // tA consumed (the next GEMM-1 epilogue rewrites it), tE complete
         mark(7);
-        // no barrier here (see msg8_split_kernel)
     }
 }
 
