@@ -266,18 +266,28 @@ __device__ __forceinline__ void mma_rb_split(const char *tile, int rb, const WFr
 // LayerNorm statistics fused into a GEMM epilogue (8 wavefronts x 16 columns): each wavefront reduces its 16 columns
 // of a row to (mean, M2) over the 4 lane quarters (Chan merge), the 8 partials per row meet in LDS [row][16].
 // ------------------------------------------------------------------------------------------------
+// The merge partners (lanes l ^ 16, then l ^ 32) are fetched with gfx950's v_permlane16_swap / v_permlane32_swap (VALU,
+// no LDS-crossbar round trip): swapping a register with itself leaves {even rows, even rows} in one result and {odd
+// rows, odd rows} in the other, and the merge is symmetric, so every lane gets the pair's result without a select.
 __device__ __forceinline__ void row_stats_partial1b(const f4 v, float *stat_slot, int q) {
     float mean = (v.x + v.y + v.z + v.w) * 0.25f;
     const f4 d = v - mean;
     float m2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
-    float n = 4.f;
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-        const float mo = __shfl_xor(mean, off), m2o = __shfl_xor(m2, off);
-        const float delta = mo - mean;
-        mean = 0.5f * (mean + mo);
-        m2 = m2 + m2o + delta * delta * (0.5f * n);
-        n *= 2.f;
+    {   // lanes l and l ^ 16: 4 + 4 values
+        const auto pm = __builtin_amdgcn_permlane16_swap(__float_as_uint(mean), __float_as_uint(mean), false, false);
+        const auto p2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(m2), __float_as_uint(m2), false, false);
+        const float ma = __uint_as_float(pm[0]), mb = __uint_as_float(pm[1]);
+        const float delta = mb - ma;
+        mean = 0.5f * (ma + mb);
+        m2 = __uint_as_float(p2[0]) + __uint_as_float(p2[1]) + delta * delta * 2.0f;
+    }
+    {   // lanes l and l ^ 32: 8 + 8 values
+        const auto pm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mean), __float_as_uint(mean), false, false);
+        const auto p2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m2), __float_as_uint(m2), false, false);
+        const float ma = __uint_as_float(pm[0]), mb = __uint_as_float(pm[1]);
+        const float delta = mb - ma;
+        mean = 0.5f * (ma + mb);
+        m2 = __uint_as_float(p2[0]) + __uint_as_float(p2[1]) + delta * delta * 4.0f;
     }
     if (q == 0) { stat_slot[0] = mean; stat_slot[1] = m2; }
 }
