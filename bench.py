@@ -194,16 +194,34 @@ def main():
     eng = Engine(synthetic_state_dict(0), device, 48)
     B, L = args.proteins_per_gpu, args.length
     batch = build_batch(B, L, 100000 * rank, device)
-    out = {"ddg": torch.empty((batch["T"], 21), dtype=torch.float32, device=device)}
-    gathered = torch.empty((world * batch["T"], 21), dtype=torch.float32, device=device) if world > 1 else None
+    # N > 1: the per-step exchange (all-gather of the ddG tables over RCCL/xGMI) is asynchronous and double-buffered: the
+    # collective of step k runs on RCCL's stream under the forward of step k+1; a buffer pair is reused only after its
+    # collective has been waited for (stream-side wait, no host sync). Everything is drained inside the timed region.
+    outs = [{"ddg": torch.empty((batch["T"], 21), dtype=torch.float32, device=device)} for _ in range(2 if world > 1 else 1)]
+    out = outs[0]
+    gathered = [torch.empty((world * batch["T"], 21), dtype=torch.float32, device=device) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+    step_no = [0]
 
     def step():
+        k = step_no[0] & 1 if world > 1 else 0
+        if world > 1 and pending[k] is not None:
+            pending[k].wait()
+            pending[k] = None
         eng.ssm_forward(batch["X"], batch["S"], batch["mask"], batch["ridx"], batch["cenc"], batch["offsets"],
-                        max_len=L, out=out)
+                        max_len=L, out=outs[k])
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out["ddg"])
+            pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k]["ddg"], async_op=True)
+        step_no[0] += 1
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -233,7 +251,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1] x {B}: {B} synthetic L={L} proteins per GPU (K=48, h=128), "
                                "full 20xL SSM each, inputs resident in HBM" +
-                               ("; per-step RCCL all-gather of ddG tables" if world > 1 else ""),
+                               ("; per-step RCCL all-gather of ddG tables (asynchronous, overlapped with the next step)" if world > 1 else ""),
                    "proteins_per_gpu": B, "L": L, "K": 48, "h": 128, "preds_per_step": preds_per_step,
                    "weights": "synthetic_state_dict(seed=0)", "parallelism": f"proteins sharded x{world}",
                    "matmul": lib.tmpnn_matmul_mode().decode() + " (per-edge GEMMs: fp32 operands as split 16-bit planes, fp32 "
