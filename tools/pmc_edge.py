@@ -16,4 +16,4 @@ for abl in (0, 32, 128):
         assert lib.tmpnn_ablate_enc_edge(eng.w.handle, 0, _ptr(P), _ptr(x), _ptr(E_idx), T, abl, _stream()) == 0
     torch.cuda.synchronize()
     outs[abl] = x
-print("max diff 8-wave vs bf3:", float((outs[32] - outs[128]).abs().max()))
+print("max diff fp32 8-wave vs split-precision form:", float((outs[32] - outs[128]).abs().max()))
