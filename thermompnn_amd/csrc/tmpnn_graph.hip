@@ -41,63 +41,58 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 }
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
-__global__ __launch_bounds__(TM_THREADS) void knn_kernel(const float *__restrict__ X, const float *__restrict__ mask,
-                                                         const int32_t *__restrict__ offsets, int N, int T, int max_len,
-                                                         int K, int32_t *__restrict__ E_idx, float *__restrict__ D_nb) {
-    extern __shared__ __attribute__((aligned(16))) float knn_lds[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float *d = knn_lds + (size_t)wv * max_len;
+// One row of the k-NN graph by one wavefront. LONG rows (L > 512) pad the LDS row by one float per 64 elements (knn_slot)
+// so that a lane's stripe (j = lane, lane + 64, ...) sits in consecutive banks, and re-scan the retired element's stripe
+// with the WHOLE wavefront (one conflict-free read, one DPP min); short rows let the owner lane re-scan its <= 8 elements.
+template <bool LONG>
+__device__ __forceinline__ void knn_row(float *d, const float *__restrict__ X, const float *__restrict__ mask, int i, int s,
+                                        int L, int Keff, int lane, int32_t *__restrict__ E_idx, float *__restrict__ D_nb) {
+    auto slot = [](int j) { return LONG ? j + (j >> 6) : j; };
+    const float xi = X[(size_t)i * 12 + 3], yi = X[(size_t)i * 12 + 4], zi = X[(size_t)i * 12 + 5];
+    const float mi = mask[i];
 
-    for (int i = blockIdx.x * 4 + wv; i < T; i += gridDim.x * 4) {
-        int lo = 0, hi = N;                      // protein p with offsets[p] <= i < offsets[p+1]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (offsets[mid] <= i) lo = mid; else hi = mid;
-        }
-        const int s = offsets[lo], L = offsets[lo + 1] - s;
-        const int Keff = K < L ? K : L;
-        const float xi = X[(size_t)i * 12 + 3], yi = X[(size_t)i * 12 + 4], zi = X[(size_t)i * 12 + 5];
-        const float mi = mask[i];
-
-        float dmax = 0.f;
+    float dmax = 0.f;
 #pragma unroll 4
-        for (int j = lane; j < L; j += 64) {
-            const float *c = X + (size_t)(s + j) * 12 + 3;
-            const float dx = c[0] - xi, dy = c[1] - yi, dz = c[2] - zi;
-            const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            const float D = __fmul_rn(mi * mask[s + j], sqrtf(__fadd_rn(s2, 1e-6f)));
-            d[j] = D;
-            dmax = fmaxf(dmax, D);
-        }
-        dmax = wave_max_f32(dmax);
-        // per-lane running minimum over its stripe (j = lane, lane + 64, ...): (distance bits, index), lowest index on ties.
-        // Distances are >= +0, so their bit patterns order like the values and a 32-bit unsigned min suffices.
-        unsigned best_d = 0xffffffffu, best_j = 0xffffffffu;
+    for (int j = lane; j < L; j += 64) {
+        const float *c = X + (size_t)(s + j) * 12 + 3;
+        const float dx = c[0] - xi, dy = c[1] - yi, dz = c[2] - zi;
+        const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        const float D = __fmul_rn(mi * mask[s + j], sqrtf(__fadd_rn(s2, 1e-6f)));
+        d[slot(j)] = D;
+        dmax = fmaxf(dmax, D);
+    }
+    dmax = wave_max_f32(dmax);
+    // per-lane running minimum over its stripe (j = lane, lane + 64, ...): (distance bits, index), lowest index on ties.
+    // Distances are >= +0, so their bit patterns order like the values and a 32-bit unsigned min suffices.
+    unsigned best_d = 0xffffffffu, best_j = 0xffffffffu;
 #pragma unroll 4
-        for (int j = lane; j < L; j += 64) {
-            const float m2 = mi * mask[s + j];
-            const float Da = __fadd_rn(d[j], __fmul_rn(1.0f - m2, dmax));
-            d[j] = Da;
-            const unsigned bits = __float_as_uint(Da);
-            if (bits < best_d) { best_d = bits; best_j = (unsigned)j; }
+    for (int j = lane; j < L; j += 64) {
+        const float m2 = mi * mask[s + j];
+        const float Da = __fadd_rn(d[slot(j)], __fmul_rn(1.0f - m2, dmax));
+        d[slot(j)] = Da;
+        const unsigned bits = __float_as_uint(Da);
+        if (bits < best_d) { best_d = bits; best_j = (unsigned)j; }
+    }
+    wave_lds_fence();
+    const int stripe_len = (L + 63) >> 6;
+    int out_j = -1;                                              // lane t keeps the t-th neighbour: one coalesced store per row
+    float out_d = 0.f;
+    for (int t = 0; t < Keff; ++t) {
+        const unsigned g = wave_min_u32(best_d);
+        const unsigned long long tied = __ballot(best_d == g);
+        unsigned j;
+        if (__popcll(tied) == 1) {                               // the common case: one lane holds the minimum
+            j = __builtin_amdgcn_readlane(best_j, (int)__ffsll((long long)tied) - 1);
+        } else {                                                 // exact tie between lanes: lowest index wins
+            j = wave_min_u32(best_d == g ? best_j : 0xffffffffu);
         }
-        wave_lds_fence();
-        int out_j = -1;                                          // lane t keeps the t-th neighbour: one coalesced store per row
-        float out_d = 0.f;
-        for (int t = 0; t < Keff; ++t) {
-            const unsigned g = wave_min_u32(best_d);
-            const unsigned long long tied = __ballot(best_d == g);
-            unsigned j;
-            if (__popcll(tied) == 1) {                           // the common case: one lane holds the minimum
-                j = __builtin_amdgcn_readlane(best_j, (int)__ffsll((long long)tied) - 1);
-            } else {                                             // exact tie between lanes: lowest index wins
-                j = wave_min_u32(best_d == g ? best_j : 0xffffffffu);
-            }
-            if (lane == t) {
-                out_j = s + (int)j;
-                out_d = __uint_as_float(g);
-            }
-            if ((j & 63u) == (unsigned)lane) {                   // owner lane retires j and rescans its stripe
+        if (lane == t) {
+            out_j = s + (int)j;
+            out_d = __uint_as_float(g);
+        }
+        const unsigned o = j & 63u;                              // owner lane of j's stripe
+        if (!LONG) {
+            if (lane == (int)o) {                                // owner lane retires j and rescans its stripe
                 d[j] = __uint_as_float(0x7f800000u);
                 best_d = 0xffffffffu;
                 best_j = 0xffffffffu;
@@ -107,12 +102,54 @@ __global__ __launch_bounds__(TM_THREADS) void knn_kernel(const float *__restrict
                     if (bits != 0x7f800000u && bits < best_d) { best_d = bits; best_j = (unsigned)jj; }
                 }
             }
+        } else {
+            if (lane == 0) d[slot((int)j)] = __uint_as_float(0x7f800000u);
+            wave_lds_fence();
+            unsigned nb = 0xffffffffu, nj = 0xffffffffu;
+            for (int k0 = 0; k0 < stripe_len; k0 += 64) {        // one pass for L <= 4096
+                const int jj = (int)o + 64 * (k0 + lane);
+                unsigned bits = 0xffffffffu;
+                if (k0 + lane < stripe_len && jj < L) {
+                    bits = __float_as_uint(d[slot(jj)]);
+                    if (bits == 0x7f800000u) bits = 0xffffffffu; // retired
+                }
+                const unsigned m = wave_min_u32(bits);
+                if (m < nb) {                                    // wavefront-uniform
+                    nb = m;
+                    const unsigned long long hit = __ballot(bits == m);
+                    nj = o + 64u * (unsigned)(k0 + (int)__ffsll((long long)hit) - 1);
+                }
+            }
+            if (lane == (int)o) {
+                best_d = nb;
+                best_j = nb == 0xffffffffu ? 0xffffffffu : nj;
+            }
         }
-        if (lane < TM_KS) {                                      // slots >= Keff keep (-1, 0)
-            E_idx[(size_t)i * TM_KS + lane] = out_j;
-            D_nb[(size_t)i * TM_KS + lane] = out_d;
+    }
+    if (lane < TM_KS) {                                          // slots >= Keff keep (-1, 0)
+        E_idx[(size_t)i * TM_KS + lane] = out_j;
+        D_nb[(size_t)i * TM_KS + lane] = out_d;
+    }
+    wave_lds_fence();
+}
+
+__global__ __launch_bounds__(TM_THREADS, 8) void knn_kernel(const float *__restrict__ X, const float *__restrict__ mask,
+                                                            const int32_t *__restrict__ offsets, int N, int T, int max_len,
+                                                            int K, int32_t *__restrict__ E_idx, float *__restrict__ D_nb) {
+    extern __shared__ __attribute__((aligned(16))) float knn_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *d = knn_lds + (size_t)wv * (max_len + (max_len >> 6) + 1);
+
+    for (int i = blockIdx.x * 4 + wv; i < T; i += gridDim.x * 4) {
+        int lo = 0, hi = N;                      // protein p with offsets[p] <= i < offsets[p+1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (offsets[mid] <= i) lo = mid; else hi = mid;
         }
-        wave_lds_fence();
+        const int s = offsets[lo], L = offsets[lo + 1] - s;
+        const int Keff = K < L ? K : L;
+        if (L > 512) knn_row<true>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
+        else knn_row<false>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
     }
 }
 
@@ -561,7 +598,7 @@ int launch_centrality(const float *X, const float *mask, const int32_t *offsets,
 
 int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,
                int32_t *E_idx, float *D_nb, hipStream_t st) {
-    const size_t lds = (size_t)4 * max_len * sizeof(float);
+    const size_t lds = (size_t)4 * (max_len + (max_len >> 6) + 1) * sizeof(float);   // knn_slot padding
     if (lds > 160 * 1024) return tm_set_error(TMPNN_E_UNSUPPORTED, "knn_topk: max_len %d needs %zu B of LDS", max_len, lds);
     static bool attr_set = false;
     if (!attr_set) {
