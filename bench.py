@@ -159,8 +159,8 @@ def cpu_baseline(batch, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)      # the clocks settle over the first ~15 forwards
     ap.add_argument("--proteins-per-gpu", type=int, default=64)
     ap.add_argument("--length", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
