@@ -72,7 +72,7 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("TMPNN_LIB") or LIB_PATH      # TMPNN_LIB: an A/B build (thermompnn_amd/build.py --variant)
     # torch ships its own copy of the ROCm runtime (libamdhip64); it must be the one already mapped when libtmpnn.so
     # resolves its HIP symbols, otherwise two runtimes coexist and the second one sees no device.
     import torch  # noqa: F401

@@ -10,9 +10,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtmpnn.so")
-SOURCES = ["tmpnn_api.hip", "tmpnn_graph.hip", "tmpnn_layers.hip", "tmpnn_head.hip", "tmpnn_split.hip", "tmpnn_pdb.cpp"]
+SOURCES = ["tmpnn_api.hip", "tmpnn_graph.hip", "tmpnn_layers.hip", "tmpnn_head.hip", "tmpnn_split.hip", "tmpnn_wt.hip", "tmpnn_pdb.cpp"]
 HEADERS = ["tmpnn_common.h", "tmpnn_split.h", "tmpnn_internal.h", os.path.join("..", "..", "include", "tmpnn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
+# kernels only (.hip): no sNaN-quieting "v_max x, x" in front of every v_min / v_max (the GELU clamps). Device code never
+# relies on NaNs (range checks test the exponent bits); the host-side PDB reader (.cpp) does and keeps IEEE semantics.
+DEVICE_FLAGS = ["-mno-amdgpu-ieee", "-fno-honor-nans"]
 
 
 def _hipcc() -> str:
@@ -30,27 +33,44 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB, tag: str = "", only=()) -> str:
+    """``extra_flags`` / ``out`` / ``tag`` build an A/B variant (e.g. ``-DWT_PIPE=0``) beside the shipped library;
+    select it at run time with TMPNN_LIB=<path> (thermompnn_amd/_lib.py)."""
+    if not force and out == LIB and not needs_build():
         return LIB
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+        if only and s not in only:          # variant of a few files: link the shipped objects of the others
+            objs.append(os.path.join(CSRC, os.path.splitext(s)[0] + ".o"))
+            continue
+        o = os.path.join(CSRC, os.path.splitext(s)[0] + tag + ".o")
         objs.append(o)
-        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [_hipcc(), *FLAGS, *(DEVICE_FLAGS if s.endswith(".hip") else []), *extra_flags, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
-        out, _ = p.communicate()
+        log, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
-        if verbose and out.strip():
-            print(out, file=sys.stderr)
-    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], check=True)
-    return LIB
+            raise RuntimeError(f"hipcc failed on {s}:\n{log}")
+        if verbose and log.strip():
+            print(log, file=sys.stderr)
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out], check=True)
+    if tag:
+        for o in objs:
+            if o.endswith(tag + ".o"):
+                os.remove(o)
+    return out
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    # python -m thermompnn_amd.build [--force] [--variant NAME -DFLAG ...]  (variant -> thermompnn_amd/libtmpnn_NAME.so)
+    if "--variant" in sys.argv:
+        k = sys.argv.index("--variant")
+        name, flags = sys.argv[k + 1], sys.argv[k + 2:]
+        only = [f[7:] for f in flags if f.startswith("--only=")]      # --only=tmpnn_wt.hip: recompile just that file
+        flags = [f for f in flags if not f.startswith("--only=")]
+        print(build_library(force=True, verbose=True, extra_flags=flags, out=os.path.join(HERE, f"libtmpnn_{name}.so"), tag="." + name, only=only))
+    else:
+        print(build_library(force="--force" in sys.argv, verbose=True))

@@ -173,9 +173,9 @@ extern "C" int64_t tmpnn_tensor_numel(int i) {
 }
 
 static const size_t POS_TABLE_FLOATS = 66 * TMPNN_HID, SEQ_TABLE_FLOATS = TMPNN_VOCAB * TMPNN_HID,
-                    CONV_CENTER_FLOATS = 384 * 384;
+                    CONV_CENTER_FLOATS = 384 * 384, W13L_BYTES = 32768;
 extern "C" size_t tmpnn_weights_packed_bytes(void) {
-    return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float);
+    return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float) + 3 * W13L_BYTES;
 }
 
 extern "C" int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *tensors, int n_tensors, void *packed,
@@ -251,8 +251,10 @@ extern "C" int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *t
     float *p = (float *)packed;
     w->pos_table = p; p += POS_TABLE_FLOATS;
     for (int l = 0; l < 3; ++l) { w->seq_table[l] = p; p += SEQ_TABLE_FLOATS; }
-    w->conv_center = p;
+    w->conv_center = p; p += CONV_CENTER_FLOATS;
+    for (int l = 0; l < 3; ++l) w->enc[l].W13l = (const char *)p + (size_t)l * W13L_BYTES;
     int rc = launch_prep_tables(w, (hipStream_t)stream);
+    for (int l = 0; l < 3 && rc == TMPNN_OK; ++l) rc = launch_wt_prep(w->enc[l].W13, (char *)w->enc[l].W13l, (hipStream_t)stream);
     if (rc != TMPNN_OK) { delete w; return rc; }
     *out = w;
     return TMPNN_OK;

@@ -96,22 +96,41 @@ __device__ __forceinline__ float gelu1(float x) {
 // Two values at a time: the Horner chain, the scalings and the final products run as packed fp32 ops
 // (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes-worth of fp32 per issue slot) — same arithmetic as gelu1.
 typedef float f2 __attribute__((ext_vector_type(2)));
+// gelu(x) = max(x, 0) - u h(u),  u = min(|x|, 4 sqrt2),  h(u) = 0.5 erfc(u / sqrt2) = exp2(u B(u) - 1): B = the degree-8 fit above
+// with the 1/sqrt2 folded into its coefficients (tools/fit_gelu.py; max abs error 2.4e-7 in emulated fp32, the rounding
+// floor of x Phi(x)). Per value: v_min (|x| as a source modifier), 9 Horner steps + 1 (packed two values at a time),
+// v_exp, v_max and one fma with a negated source. For |x| > 4 sqrt2 the clamped u also stands in for |x| in the product: u h(u) < 4.4e-8 there.
+#ifndef TM_GELU_ASM
+#define TM_GELU_ASM 1
+#endif
+// One packed Horner step q <- q t + c, c broadcast from the low half of an SGPR pair. Written as inline asm because hipcc
+// splits about a third of these v_pk_fma_f32 back into two v_fma_f32 when they sit near MFMAs — sensible for an
+// MFMA-bound loop, but these kernels are VALU-issue-bound and a packed op costs the same ~4 cycles as a scalar one.
+// (Operands are VALU-produced values only, so no MFMA read hazard hides inside the asm.)
+__device__ __forceinline__ f2 pk_horner(f2 q, f2 t, float c) {
+#if TM_GELU_ASM
+    f2 r;
+    const unsigned long long cc = (unsigned long long)__float_as_uint(c);
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(r) : "v"(q), "v"(t), "s"(cc));
+    return r;
+#else
+    return __builtin_elementwise_fma(q, t, f2{c, c});
+#endif
+}
 __device__ __forceinline__ f2 gelu2(f2 x) {
-    // |x| rides on the multiply as a source modifier; x Phi(x) = max(x, 0) - |x| h  (h = 0.5 erfc(|x|/sqrt2)) needs no
-    // sign transfer: one v_max and one v_fma (with -|x| modifiers) per value
-    const f2 t = f2{fminf(fabsf(x.x) * 0.70710678118654752440f, 4.0f), fminf(fabsf(x.y) * 0.70710678118654752440f, 4.0f)};
-    f2 q = f2{2.814671218e-06f, 2.814671218e-06f};
-    q = __builtin_elementwise_fma(q, t, f2{-5.093904975e-05f, -5.093904975e-05f});
-    q = __builtin_elementwise_fma(q, t, f2{3.626021436e-04f, 3.626021436e-04f});
-    q = __builtin_elementwise_fma(q, t, f2{-1.058569948e-03f, -1.058569948e-03f});
-    q = __builtin_elementwise_fma(q, t, f2{-1.620148622e-03f, -1.620148622e-03f});
-    q = __builtin_elementwise_fma(q, t, f2{2.903427724e-02f, 2.903427724e-02f});
-    q = __builtin_elementwise_fma(q, t, f2{-1.488050018e-01f, -1.488050018e-01f});
-    q = __builtin_elementwise_fma(q, t, f2{-9.183712091e-01f, -9.183712091e-01f});
-    q = __builtin_elementwise_fma(q, t, f2{-1.627908858e+00f, -1.627908858e+00f});
-    const f2 e = __builtin_elementwise_fma(q, t, f2{-1.0f, -1.0f});
-    return f2{fmaf(-fabsf(x.x), __builtin_amdgcn_exp2f(e.x), fmaxf(x.x, 0.f)),
-              fmaf(-fabsf(x.y), __builtin_amdgcn_exp2f(e.y), fmaxf(x.y, 0.f))};
+    const f2 t = f2{fminf(fabsf(x.x), 5.656854249f), fminf(fabsf(x.y), 5.656854249f)};
+    f2 q = __builtin_elementwise_fma(f2{1.243920691e-07f, 1.243920691e-07f}, t, f2{-3.183690609e-06f, -3.183690609e-06f});
+    q = pk_horner(q, t, 3.204980433e-05f);
+    q = pk_horner(q, t, -1.323212435e-04f);
+    q = pk_horner(q, t, -2.864045193e-04f);
+    q = pk_horner(q, t, 7.258569310e-03f);
+    q = pk_horner(q, t, -5.261051294e-02f);
+    q = pk_horner(q, t, -4.591856045e-01f);
+    q = pk_horner(q, t, -1.151105393e+00f);
+    const f2 e = pk_horner(q, t, -1.0f);
+    // the library is built with -mno-amdgpu-ieee -fno-honor-nans: fminf / fmaxf are single v_min / v_max (no canonicalising
+    // v_max x, x in front of each)
+    return f2{fmaf(-t.x, __builtin_amdgcn_exp2f(e.x), fmaxf(x.x, 0.f)), fmaf(-t.y, __builtin_amdgcn_exp2f(e.y), fmaxf(x.y, 0.f))};
 }
 __device__ __forceinline__ f4 gelu4(f4 v) {
     const f2 a = gelu2(f2{v.x, v.y}), b = gelu2(f2{v.z, v.w});
