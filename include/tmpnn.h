@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TMPNN_VERSION 100
+#define TMPNN_VERSION 200
 #define TMPNN_HID 128          /* hidden width (transfer_model.py:19) */
 #define TMPNN_KS 48            /* neighbour slots per residue */
 #define TMPNN_VOCAB 21
@@ -42,7 +42,17 @@ enum {
     TMPNN_E_INVALID = -1,      /* bad argument (null pointer, negative size, K out of range ...) */
     TMPNN_E_UNSUPPORTED = -2,  /* valid request outside what this build supports */
     TMPNN_E_LAUNCH = -3,       /* HIP launch/runtime error (message has hipGetErrorString) */
-    TMPNN_E_WORKSPACE = -4     /* workspace / packed buffer too small */
+    TMPNN_E_WORKSPACE = -4,    /* workspace / packed buffer too small */
+    TMPNN_E_RANGE = -5         /* a result left the finite range (tmpnn_status_error); retry with precision "bf16x3" */
+};
+
+/* Device-side status word (int32, caller-owned device memory, optional): kernels OR these bits in; the library never
+ * reads it back (no stream sync). The host copies it after synchronising and passes it to tmpnn_status_error(). */
+enum {
+    TMPNN_STATUS_RANGE = 1,    /* a ddG / log-probability is inf or NaN: an activation or weight overflowed the fp16 range of
+                                  the "f16x2" matrix-core path (|x| >= 65504) */
+    TMPNN_STATUS_MAXLEN = 2    /* a protein is longer than the max_len the caller passed: its neighbour rows were left
+                                  empty (E_idx = -1) instead of overrunning the kernel's per-row scratch */
 };
 
 typedef struct tmpnn_weights tmpnn_weights_t;   /* opaque; immutable after create */
@@ -50,12 +60,16 @@ typedef void *tmpnn_stream_t;                   /* hipStream_t */
 
 int tmpnn_version(void);
 const char *tmpnn_last_error(void);
+/* Maps a status word (host copy) to an error: 0 -> TMPNN_OK; TMPNN_STATUS_MAXLEN -> TMPNN_E_INVALID;
+ * TMPNN_STATUS_RANGE -> TMPNN_E_RANGE (message in tmpnn_last_error()). */
+int tmpnn_status_error(int32_t status);
 /* "f16x2" (default), "bf16x3" or "fp32": how the per-edge GEMMs (featurizer, message and edge-update kernels) run on
  * the matrix cores. f16x2 = every fp32 operand kept as two fp16 values x = h + l*2^-11 (22 significant bits), three
  * partial products per term on v_mfma_f32_16x16x32_f16 with fp32 accumulation; bf16x3 = exact three-way bf16 split, six
  * partial products on v_mfma_f32_16x16x32_bf16 (full fp32 range); fp32 = v_mfma_f32_16x16x4_f32. All three are in the
  * same accuracy class (see thermompnn_amd/csrc/tmpnn_split.h) and pass the same parity tests.
- * Selected once per process by the environment variable TMPNN_PRECISION. */
+ * The precision is a property of the WEIGHT HANDLE (tmpnn_weights_create_p); this call returns the default that
+ * handles created without an explicit precision get (environment variable TMPNN_PRECISION, else "f16x2"). */
 const char *tmpnn_matmul_mode(void);
 
 /* ---- weights ------------------------------------------------------------------------------------
@@ -79,6 +93,12 @@ size_t tmpnn_weights_packed_bytes(void);
  * `stream`. */
 int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *tensors, int n_tensors,
                          void *packed, size_t packed_bytes, tmpnn_stream_t stream);
+/* Same, with the matrix-core precision of every call made through this handle: "f16x2" | "bf16x3" | "fp32", or NULL
+ * for the default. Unknown names return TMPNN_E_INVALID. Several handles (e.g. one per precision) may share the raw
+ * tensors; each needs its own `packed` buffer. */
+int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const *tensors, int n_tensors,
+                           void *packed, size_t packed_bytes, const char *precision, tmpnn_stream_t stream);
+const char *tmpnn_weights_precision(const tmpnn_weights_t *w);
 void tmpnn_weights_destroy(tmpnn_weights_t *w);
 
 /* ---- graph construction ------------------------------------------------------------------------
@@ -86,9 +106,11 @@ void tmpnn_weights_destroy(tmpnn_weights_t *w);
  * X [T,4,3] (N,CA,C,O; NaN already zeroed as tied_featurize does, :577), mask [T].
  * E_idx [T,48] receives GLOBAL packed row indices sorted by ascending adjusted distance (ties: lower
  * index first), -1 in invalid slots; D_nb [T,48] the adjusted distances (0 in invalid slots).
- * max_len = max_p L_p (sizes the per-row LDS scratch; must be <= 8192). */
+ * max_len >= max_p L_p sizes the per-row LDS scratch (1 <= max_len <= 8192). The lengths live in device memory, so the
+ * host cannot check them: a protein longer than max_len gets empty rows and TMPNN_STATUS_MAXLEN in *status_opt. */
 int tmpnn_knn_topk(const float *X, const float *mask, const int32_t *offsets, int n_proteins,
-                   int64_t T, int max_len, int K, int32_t *E_idx, float *D_nb, tmpnn_stream_t stream);
+                   int64_t T, int max_len, int K, int32_t *E_idx, float *D_nb, int32_t *status_opt,
+                   tmpnn_stream_t stream);
 
 /* compute_centrality (analysis/thermompnn_benchmarking.py:20-35): out[t] = #{other residues of the same protein
  * with |CA_t - CA_j| < radius}; residues without coordinates (mask 0) get -1 and are never counted. int32 [T]. */
@@ -137,7 +159,7 @@ int tmpnn_seq_embed(const tmpnn_weights_t *w, const int32_t *S, int64_t T, float
                     tmpnn_stream_t stream);
 /* log_softmax(W_out h_V + b) (protein_mpnn_utils.py:1275-1276) -> [T,21]. */
 int tmpnn_log_probs(const tmpnn_weights_t *w, const float *h_V, int64_t T, float *log_probs,
-                    tmpnn_stream_t stream);
+                    int32_t *status_opt, tmpnn_stream_t stream);
 
 /* ---- ddG head ------------------------------------------------------------------------------------
  * TransferModel.forward's per-mutation body (transfer_model.py:86-120) evaluated once per POSITION:
@@ -145,18 +167,20 @@ int tmpnn_log_probs(const tmpnn_weights_t *w, const float *h_V, int64_t T, float
  * length-1 sequence), z = both_out(y) (:67-71). ddg [T,21]: ddg[t,a] = (w z_a + b) - (w z_S[t] + b)
  * (:110-116); z_opt (may be NULL) receives z [T,21]. */
 int tmpnn_ddg_head(const tmpnn_weights_t *w, const float *hV_last, const float *hV_prev,
-                   const int32_t *S, int64_t T, float *ddg, float *z_opt, tmpnn_stream_t stream);
+                   const int32_t *S, int64_t T, float *ddg, float *z_opt, int32_t *status_opt,
+                   tmpnn_stream_t stream);
 
 /* ---- the fused path ------------------------------------------------------------------------------
  * Everything TransferModel.forward does on the device for a ragged batch of N proteins
  * (transfer_model.py:75-121 + protein_mpnn_utils.py:1222-1277), one call, ~30 launches on `stream`.
  * Outputs (each may be NULL except ddg): ddg [T,21]; hidden_opt [3,T,128] = decoder states 1..3
- * (the reference returns them reversed, :1277); log_probs_opt [T,21]; E_idx_opt [T,48] global rows. */
+ * (the reference returns them reversed, :1277); log_probs_opt [T,21]; E_idx_opt [T,48] global rows.
+ * status_opt (device int32, may be NULL) is zeroed on the stream and then receives TMPNN_STATUS_* bits. */
 int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const int32_t *S, const float *mask,
                       const int32_t *residue_idx, const int32_t *chain_enc, const int32_t *offsets,
                       int n_proteins, int64_t T, int max_len, int K, float *ddg, float *hidden_opt,
-                      float *log_probs_opt, int32_t *E_idx_opt, void *workspace, size_t workspace_bytes,
-                      tmpnn_stream_t stream);
+                      float *log_probs_opt, int32_t *E_idx_opt, int32_t *status_opt, void *workspace,
+                      size_t workspace_bytes, tmpnn_stream_t stream);
 
 /* ---- host side: native PDB reader + packer ------------------------------------------
  * Replaces alt_parse_PDB (protein_mpnn_utils.py:183-350) + the packing of tied_featurize (:353-605) for one
@@ -172,34 +196,11 @@ int64_t tmpnn_pdb_length(const tmpnn_pdb_t *p);      /* total residues L over th
 int tmpnn_pdb_num_chains(const tmpnn_pdb_t *p);
 /* Any output may be NULL. X [L,4,3] fp32 with NaN -> 0, S [L] (ALPHABET index, gap -> 20), mask [L] (1 = all
  * four backbone atoms present), residue_idx [L] = 100 (c-1) + position, chain_enc [L] = c (1-based),
- * seq [L+1] = the parser's one-letter sequence ('-' at numbering gaps / unknown residues), NUL-terminated. */
+ * seq [L+1] = the parser's one-letter sequence ('-' at numbering gaps / unknown residues), NUL-terminated,
+ * ca_mask [L] (1 = the CA atom is present: the mask compute_centrality uses, thermompnn_benchmarking.py:20-27). */
 int tmpnn_pdb_fill(const tmpnn_pdb_t *p, float *X, int32_t *S, float *mask, int32_t *residue_idx,
-                   int32_t *chain_enc, char *seq);
+                   int32_t *chain_enc, char *seq, float *ca_mask);
 void tmpnn_pdb_free(tmpnn_pdb_t *p);
-
-/* ---- measurement hook ------------------------------------------------------------------------------
- * Optional per-kernel timing with HIP events recorded on the launch stream around every kernel the
- * library launches (bench.py's roofline leg; not thread-safe; off by default). enable(1) starts a
- * fresh recording, enable(0) stops. fetch() waits for the recorded events, aggregates by kernel name
- * into the caller's arrays (up to `capacity` rows, names are static strings), clears the recording and
- * returns the number of rows (or a negative error). */
-int tmpnn_profile_enable(int on);
-/* Timing experiments only: launches the encoder edge-update kernel by itself with parts disabled
- * (ablation bitmask 1 no global loads, 2 no GELU, 4 no LayerNorm/store, 8 no MFMA; 0 = the real kernel).
- * Results are meaningless for ablation != 0. */
-int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const float *P, float *h_E, const int32_t *E_idx,
-                          int64_t T, int ablation, tmpnn_stream_t stream);
-int tmpnn_profile_fetch(const char **names, double *total_ms, int64_t *launches, int capacity);
-
-/* GEMM core probe: Y[t] = reps x (X[t] W^T) for T tiles of [48,128] and one [128,128] weight; mode 0 = exact fp32 MFMA,
- * mode 1 = six-term bf16x3 split MFMA, mode 2 = three-term f16x2 split MFMA (tmpnn_split.h). For accuracy / speed
- * comparisons of the matrix-core paths. */
-int tmpnn_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, tmpnn_stream_t stream);
-
-/* Effective shader clock under a saturated fp32-MFMA stream (192 v_mfma_f32_16x16x4_f32 per iteration per wavefront,
- * 4 wavefronts per workgroup): out[2b] = shader cycles of workgroup b, out[2b+1] = the same interval in 100 MHz ticks.
- * `sink` (>= 256 floats) keeps the result live. */
-int tmpnn_clock_probe(int blocks, int iters, uint64_t *out, float *sink, tmpnn_stream_t stream);
 
 #ifdef __cplusplus
 }

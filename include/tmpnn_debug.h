@@ -1,0 +1,42 @@
+/*
+ * tmpnn_debug.h — measurement and experiment hooks of libtmpnn.so. NOT part of the operator boundary (include/tmpnn.h):
+ * nothing in the product path calls these; bench.py (per-kernel HIP-event timing for the roofline leg) and the scripts
+ * under tools/ do.
+ */
+#ifndef TMPNN_DEBUG_H
+#define TMPNN_DEBUG_H
+
+#include "tmpnn.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- per-kernel timing ----------------------------------------------------------------------------
+ * Optional per-kernel timing with HIP events recorded on the launch stream around every kernel the
+ * library launches (bench.py's roofline leg; not thread-safe; off by default). enable(1) starts a
+ * fresh recording, enable(0) stops. fetch() waits for the recorded events, aggregates by kernel name
+ * into the caller's arrays (up to `capacity` rows, names are static strings), clears the recording and
+ * returns the number of rows (or a negative error). */
+int tmpnn_profile_enable(int on);
+/* Timing experiments only: launches the encoder edge-update kernel by itself with parts disabled
+ * (ablation bitmask 1 no global loads, 2 no GELU, 4 no LayerNorm/store, 8 no MFMA; 0 = the real kernel).
+ * Results are meaningless for ablation != 0. */
+int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const float *P, float *h_E, const int32_t *E_idx,
+                          int64_t T, int ablation, tmpnn_stream_t stream);
+int tmpnn_profile_fetch(const char **names, double *total_ms, int64_t *launches, int capacity);
+
+/* GEMM core probe: Y[t] = reps x (X[t] W^T) for T tiles of [48,128] and one [128,128] weight; mode 0 = exact fp32 MFMA,
+ * mode 1 = six-term bf16x3 split MFMA, mode 2 = three-term f16x2 split MFMA (tmpnn_split.h). For accuracy / speed
+ * comparisons of the matrix-core paths. */
+int tmpnn_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, tmpnn_stream_t stream);
+
+/* Effective shader clock under a saturated fp32-MFMA stream (192 v_mfma_f32_16x16x4_f32 per iteration per wavefront,
+ * 4 wavefronts per workgroup): out[2b] = shader cycles of workgroup b, out[2b+1] = the same interval in 100 MHz ticks.
+ * `sink` (>= 256 floats) keeps the result live. */
+int tmpnn_clock_probe(int blocks, int iters, uint64_t *out, float *sink, tmpnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMPNN_DEBUG_H */

@@ -7,8 +7,8 @@ import pytest
 from conftest import REPO
 
 
-def declared_symbols():
-    text = open(os.path.join(REPO, "include", "tmpnn.h")).read()
+def declared_symbols(header="tmpnn.h"):
+    text = open(os.path.join(REPO, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(tmpnn_[a-z0-9_]+)\s*\(", text)))
 
@@ -23,6 +23,12 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, n), f"libtmpnn.so does not export {n}"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
+    # the measurement hooks live in their own header, outside the operator boundary
+    dbg = declared_symbols("tmpnn_debug.h")
+    assert sorted(_lib.DEBUG_SIGNATURES) == dbg and not set(dbg) & set(names)
+    for n in dbg:
+        assert hasattr(lib, n), f"libtmpnn.so does not export {n}"
+    assert not [n for n in names if "probe" in n or "ablate" in n or "profile" in n]
 
 
 def test_tensor_table_matches_python_state_dict_order():
@@ -37,22 +43,34 @@ def test_tensor_table_matches_python_state_dict_order():
             n *= s
         assert lib.tmpnn_tensor_numel(i) == n
     assert lib.tmpnn_tensor_name(130) is None and lib.tmpnn_tensor_numel(-1) == -1
-    assert lib.tmpnn_version() == 100
+    assert lib.tmpnn_version() == 200
     assert lib.tmpnn_workspace_bytes(256) > 256 * 48 * 128 * 4
-    assert lib.tmpnn_weights_packed_bytes() == (66 * 128 + 3 * 21 * 128 + 384 * 384) * 4
+    assert lib.tmpnn_weights_packed_bytes() == (66 * 128 + 3 * 21 * 128 + 384 * 384) * 4 + 3 * 32768
 
 
 def test_argument_errors_do_not_need_a_gpu():
     """Argument validation happens before any launch: bad calls return error codes + a message."""
     from thermompnn_amd import _lib
     lib = _lib.load()
-    rc = lib.tmpnn_knn_topk(None, None, None, 1, 10, 10, 48, None, None, None)
+    rc = lib.tmpnn_knn_topk(None, None, None, 1, 10, 10, 48, None, None, None, None)
     assert rc == -1 and b"null" in lib.tmpnn_last_error()
     rc = lib.tmpnn_gather_nodes(None, None, 1, -3, 2, 4, None, None)
     assert rc == -1 and b"bad shape" in lib.tmpnn_last_error()
     assert lib.tmpnn_gather_nodes(None, None, 0, 5, 2, 4, None, None) == 0     # empty input is OK
     with pytest.raises(_lib.TmpnnError):
         _lib.check(-2, "demo")
+    # the device status word maps to error codes on the host (no GPU needed)
+    assert lib.tmpnn_status_error(0) == 0
+    assert lib.tmpnn_status_error(_lib.STATUS_RANGE) == _lib.E_RANGE and b"bf16x3" in lib.tmpnn_last_error()
+    assert lib.tmpnn_status_error(_lib.STATUS_MAXLEN) == -1 and b"max_len" in lib.tmpnn_last_error()
+    with pytest.raises(_lib.TmpnnRangeError):
+        _lib.check(lib.tmpnn_status_error(_lib.STATUS_RANGE), "demo")
+    # precision is an argument of the weight handle; unknown names are an error code, not an abort()
+    import ctypes as C
+    h = C.c_void_p()
+    arr = (C.c_void_p * 118)(*([16] * 118))
+    rc = lib.tmpnn_weights_create_p(C.byref(h), arr, 118, C.c_void_p(16), 1 << 30, b"fp64", None)
+    assert rc == -1 and b"unknown precision" in lib.tmpnn_last_error()
     with pytest.raises(_lib.TmpnnError, match="not found"):
         _lib.load("/nonexistent/libtmpnn.so")
 

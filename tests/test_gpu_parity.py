@@ -80,7 +80,7 @@ def align(ours, ours_idx, ref, ref_idx, rows):
 def test_library_is_the_hip_build():
     from thermompnn_amd import _lib
     lib = _lib.load()
-    assert lib.tmpnn_version() == 100 and lib.tmpnn_num_tensors() == 130
+    assert lib.tmpnn_version() == 200 and lib.tmpnn_num_tensors() == 130
     with open("/proc/self/maps") as fh:
         assert "libtmpnn.so" in fh.read()
 
@@ -140,6 +140,10 @@ def test_stagewise_parity_vs_oracle(case, engine, synthetic_weights):
 @pytest.mark.parametrize("case", CASES)
 def test_fused_forward_vs_reference_golden(case, engine, synthetic_weights):
     """tmpnn_ssm_forward against the vectors the imported reference produced (tests/golden/make_golden.py)."""
+    check_fused_forward(case, engine, synthetic_weights)
+
+
+def check_fused_forward(case, engine, synthetic_weights):
     g = load_golden(case)
     p = packed_inputs(g)
     res = engine.ssm_forward(p["X"], p["S"], p["mask"], p["ridx"], p["cenc"], p["offsets"], want_hidden=True,
@@ -518,22 +522,48 @@ def test_randomised_parity_vs_oracle(K, synthetic_weights):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3", "f16x2"])
-def test_all_matmul_modes_pass_golden_parity(mode):
-    """TMPNN_PRECISION is read once per process: run the fused golden-parity tests in a child process for each mode."""
+def test_all_matmul_modes_pass_golden_parity(mode, synthetic_weights):
+    """Precision is an argument of the engine / weight handle: every matrix-core path passes the same golden parity in
+    one process, and a per-call override reproduces the dedicated engine bit for bit."""
+    from thermompnn_amd.engine import Engine
+    eng = Engine(synthetic_weights, "cuda:0", 48, precision=mode)
+    assert eng.precision == mode and eng.w.precision == mode
+    for case in CASES:
+        check_fused_forward(case, eng, synthetic_weights)
+    p = packed_inputs(load_golden("syn_L256_s1"))
+    a = eng.ssm_forward(p["X"], p["S"], p["mask"], p["ridx"], p["cenc"], p["offsets"])["ddg"]
+    other = Engine(synthetic_weights, "cuda:0", 48, precision="f16x2" if mode != "f16x2" else "bf16x3")
+    b = other.ssm_forward(p["X"], p["S"], p["mask"], p["ridx"], p["cenc"], p["offsets"], precision=mode)["ddg"]
+    assert torch.equal(a, b)
+
+
+def test_precision_default_comes_from_the_environment():
+    """TMPNN_PRECISION only picks the default of handles created without a precision (read once per process)."""
     import subprocess
     import sys
-    env = dict(os.environ, TMPNN_PRECISION=mode)
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "from thermompnn_amd import _lib; assert _lib.load().tmpnn_matmul_mode().decode() == %r\n"
-            "import pytest; sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-k', 'fused_forward or ragged_batch', %r]))"
-            % (os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0], os.path.dirname(GOLDEN), mode, __file__))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from thermompnn_amd import _lib\nfrom thermompnn_amd.engine import Engine\n"
+            "from thermompnn_amd.weights import synthetic_state_dict\n"
+            "assert _lib.load().tmpnn_matmul_mode().decode() == 'bf16x3'\n"
+            "W = synthetic_state_dict(0)\n"
+            "assert Engine(W, 'cuda:0').precision == 'bf16x3' and Engine(W, 'cuda:0', precision='fp32').precision == 'fp32'\n" % repo)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TMPNN_PRECISION="bf16x3"), capture_output=True,
+                       text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    bad_code = ("import sys; sys.path.insert(0, %r)\nfrom thermompnn_amd.engine import Engine\n"
+                "from thermompnn_amd.weights import synthetic_state_dict\nEngine(synthetic_state_dict(0), 'cuda:0')\n" % repo)
+    bad = subprocess.run([sys.executable, "-c", bad_code], env=dict(os.environ, TMPNN_PRECISION="fp64"), capture_output=True,
+                         text=True, timeout=600)
+    assert bad.returncode != 0 and "unknown precision" in bad.stderr      # an error, not an abort()
 
 
 @pytest.mark.parametrize("env", [{"TMPNN_MSG_WAVES": "4"}, {"TMPNN_MSG_WAVES": "8"}, {"TMPNN_SPLIT_DMA": "1"},
-                                 {"TMPNN_NODE_SPLIT": "0", "TMPNN_FEAT_SPLIT": "0", "TMPNN_HEAD_SPLIT": "0"}, {"TMPNN_NODE_WAVES": "4"}],
-                         ids=["msg4", "msg8", "dma_staging", "fp32_node_featurizer_head", "node4"])
+                                 {"TMPNN_NODE_SPLIT": "0", "TMPNN_FEAT_SPLIT": "0", "TMPNN_HEAD_SPLIT": "0"}, {"TMPNN_NODE_WAVES": "4"},
+                                 {"TMPNN_WT": "1", "TMPNN_WT_MIN_T": "0"}, {"TMPNN_WT": "1", "TMPNN_WT_MIN_T": "0", "TMPNN_WT_EDGE": "1"},
+                                 {"TMPNN_WT": "1", "TMPNN_WT_MIN_T": "0", "TMPNN_WT_EDGE": "1", "TMPNN_WT_WAVES": "12"}],
+                         ids=["msg4", "msg8", "dma_staging", "fp32_node_featurizer_head", "node4", "wt_msg", "wt_msg_edge",
+                              "wt_12_waves"])
 def test_selectable_kernel_forms_pass_golden_parity(env):
     """The non-default kernel forms of the f16x2 mode (selected by environment, read once per process) stay parity-green."""
     import subprocess
@@ -586,6 +616,223 @@ def test_split_precision_gemm_core_accuracy():
         errs[mode] = float(((Y.double() - ref).abs() / scale).max())
     assert errs[1] < 4e-7 and errs[1] <= 1.5 * errs[0], errs
     assert errs[2] < 6e-7 and errs[2] <= 2.5 * errs[0], errs
+
+
+def _synthetic_protein(L, seed):
+    from thermompnn_amd.synthetic import synthetic_backbone
+    X, seq = synthetic_backbone(int(L), int(seed))
+    return dict(X=X.astype(np.float32), S=np.array(["ACDEFGHIKLMNPQRSTVWY".index(c) for c in seq], dtype=np.int32),
+                mask=np.ones(L, np.float32), residue_idx=np.arange(L, dtype=np.int32), chain_enc=np.ones(L, np.int32))
+
+
+def _oracle_table(W, p):
+    from oracle import thermompnn_oracle as orc
+    L = len(p["S"])
+    ones, ar = torch.ones(1, L), torch.arange(L)[None]
+    with torch.no_grad():
+        return orc.ssm_table(W, torch.from_numpy(p["X"])[None], torch.from_numpy(p["S"].astype(np.int64))[None], ones, ones,
+                             ar, ones.long(), 48)[0].numpy()
+
+
+def test_config3_full_size_ragged_1024(engine, synthetic_weights):
+    """BASELINE.json configs[2] at FULL size: 1 024 ragged proteins, L ~ U[64, 512] (T = 295 632 residues, 8.7 GB of
+    workspace, h_E byte offsets beyond 2^32) in ONE ssm_forward. Sampled proteins — first, last, longest, shortest and
+    the ones straddling the 2^31- and 2^32-byte h_E offsets — must equal their single-protein forward bit for bit and
+    the CPU oracle to 1e-4 kcal/mol."""
+    from thermompnn_amd.dist import pack_proteins
+    lens = np.random.default_rng(1).integers(64, 513, size=1024)             # tools/run_configs.py:66-70
+    prots = [_synthetic_protein(L, 1000 + i) for i, L in enumerate(lens)]
+    b = pack_proteins(prots, list(range(1024)), "cuda:0")
+    T = int(lens.sum())
+    assert T == 295632 and T * 48 * 128 * 4 > 2 ** 32
+    ddg = engine.ssm_forward(b["X"], b["S"], b["mask"], b["ridx"], b["cenc"], b["offsets"], max_len=b["max_len"])["ddg"]
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    row_bytes = 48 * 128 * 4
+    straddle = [int(np.searchsorted(starts, (2 ** k) // row_bytes, side="right") - 1) for k in (31, 32)]
+    for k, i in zip((31, 32), straddle):
+        assert starts[i] * row_bytes < 2 ** k <= starts[i + 1] * row_bytes
+    sample = sorted({0, 1023, int(lens.argmax()), int(lens.argmin()), 511, 700, *straddle})
+    assert len(sample) >= 8
+    wt_zero = ddg.cpu().numpy()[np.arange(T), b["S"].cpu().numpy()]
+    assert (wt_zero == 0).all() and bool(torch.isfinite(ddg).all())          # a checksum over ALL 5.9 M predictions
+    for i in sample:
+        p, L = prots[i], int(lens[i])
+        mine = ddg[starts[i]:starts[i + 1]]
+        single = engine.ssm_forward(p["X"], p["S"], p["mask"], p["residue_idx"], p["chain_enc"],
+                                    torch.tensor([0, L], dtype=torch.int32))["ddg"]
+        assert torch.equal(mine, single), f"protein {i} differs from its single-protein forward"
+        np.testing.assert_allclose(mine.cpu().numpy(), _oracle_table(synthetic_weights, p), atol=TOL_DDG, rtol=0)
+
+
+def test_config4_listed_mutations(engine, synthetic_weights):
+    """BASELINE.json configs[3] on one rank: 300 Megascale-like proteins (L in [40, 72]: K_eff = min(48, L) < 48 for many)
+    and an explicit list of 200 000 (protein, position, aa) triples drawn without replacement; the product path is
+    dist.ssm_scan + dist.select_mutations. Checked against the CPU oracle on sampled proteins."""
+    from thermompnn_amd.dist import select_mutations, ssm_scan
+    rng = np.random.default_rng(2)
+    lens = rng.integers(40, 73, size=300)
+    prots = [_synthetic_protein(L, 5000 + i) for i, L in enumerate(lens)]
+    T = int(lens.sum())
+    flat = rng.choice(20 * T, size=200000, replace=False)
+    res_of = flat // 20
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    pid = np.searchsorted(starts, res_of, side="right") - 1
+    triples = np.stack([pid, res_of - starts[pid], flat % 20], 1)
+    tables = ssm_scan(engine, prots)
+    vals = select_mutations(tables, triples).cpu().numpy()
+    assert vals.shape == (200000,) and np.isfinite(vals).all()
+    assert (lens < 48).sum() > 50                                            # the K_eff < 48 path is exercised
+    for i in (0, 7, 150, 299, int(lens.argmin()), int(lens.argmax())):
+        want = _oracle_table(synthetic_weights, prots[i])
+        sel = pid == i
+        np.testing.assert_allclose(vals[sel], want[triples[sel, 1], triples[sel, 2]], atol=TOL_DDG, rtol=0)
+    with pytest.raises(IndexError):
+        select_mutations(tables, np.array([[0, 9999, 0]]))
+
+
+def _torchrun(args, env, timeout=900):
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571"] + args
+    return subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_rank_scan_with_the_real_engine(tmp_path, engine):
+    """Two ranks (both on cuda:0, gloo group — the box has one GPU) run the REAL engine through dist.ssm_scan: LPT shards,
+    one all-gather of [rows, 22] tables. Every table equals the 1-rank run bit for bit."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    worker = os.path.join(repo, "tests", "dist_worker.py")
+    one = str(tmp_path / "one.npz")
+    r1 = subprocess.run([sys.executable, worker, one, "24"], capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    two = str(tmp_path / "two.npz")
+    r2 = _torchrun([worker, two, "24"], {"TMPNN_ONE_DEVICE": "1"})
+    assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-2500:]
+    a, b = np.load(one), np.load(two)
+    assert int(a["world"]) == 1 and int(b["world"]) == 2 and (b["shard_sizes"] > 0).all()
+    for i in range(24):
+        np.testing.assert_array_equal(a[f"t{i}"], b[f"t{i}"])
+        np.testing.assert_array_equal(a[f"c{i}"], b[f"c{i}"])
+    if torch.cuda.device_count() >= 2:                                       # RCCL proper needs one GPU per rank
+        nc = str(tmp_path / "nccl.npz")
+        r3 = _torchrun([worker, nc, "24"], {})
+        assert r3.returncode == 0, r3.stdout[-1500:] + r3.stderr[-2500:]
+        c = np.load(nc)
+        for i in range(24):
+            np.testing.assert_array_equal(a[f"t{i}"], c[f"t{i}"])
+
+
+def test_two_rank_bench_and_cli(tmp_path):
+    """bench.py --gpus 2 (one-device smoke mode) prints the contract line for n_gpus = 2, and the many-PDB CLI under
+    torchrun writes the same CSV as the single-process run."""
+    import json
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    r = _torchrun([os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--proteins-per-gpu", "2"],
+                  {"TMPNN_BENCH_ONE_DEVICE": "1", "TMPNN_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["preds_per_step"] == 2 * 2 * 256 * 20
+    from thermompnn_amd import ssm_scan
+    pdbs = [os.path.join(GOLDEN, "2OCJ.pdb"), os.path.join(GOLDEN, "2OCJ_gap_chainA.pdb")]
+    single = ssm_scan.main(pdbs + ["--synthetic_weights", "0", "--centrality", "--out", str(tmp_path / "one.csv")])
+    r = _torchrun(["-m", "thermompnn_amd.ssm_scan"] + pdbs + ["--synthetic_weights", "0", "--centrality", "--out",
+                                                            str(tmp_path / "two.csv")], {"TMPNN_ONE_DEVICE": "1", "PYTHONPATH": repo})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    assert open(single).read() == open(tmp_path / "two.csv").read()
+    # an explicit mutation list selects rows of the same tables
+    mlist = tmp_path / "muts.csv"
+    mlist.write_text("pdb,position,mutation\n2OCJ,5,W\n2OCJ_gap_chainA,17,A\n2OCJ,5,A\n")
+    out = ssm_scan.main(pdbs + ["--synthetic_weights", "0", "--mutations", str(mlist), "--out", str(tmp_path / "sel.csv")])
+    import csv
+    rows = list(csv.DictReader(open(out)))
+    full = {(r_["pdb"], r_["position"], r_["mutation"]): r_["ddG_pred"] for r_ in csv.DictReader(open(single))}
+    assert [(r_["pdb"], r_["position"], r_["mutation"]) for r_ in rows] == [("2OCJ", "5", "W"), ("2OCJ_gap_chainA", "17", "A"), ("2OCJ", "5", "A")]
+    assert all(full[(r_["pdb"], r_["position"], r_["mutation"])] == r_["ddG_pred"] for r_ in rows)
+
+
+def test_range_overflow_is_detected_and_retried(synthetic_weights):
+    """f16x2 needs every GEMM operand below 65504. With W_edge scaled by 1e6 the featurizer overflows fp16: the head
+    kernel raises TMPNN_STATUS_RANGE on the device, Engine.ssm_forward reruns the batch in bf16x3 with a warning (the
+    scaled network is still finite there: the LayerNorm behind W_edge is scale-invariant) — or raises when no retry
+    precision is set. TransferModel.forward goes through the same path."""
+    import warnings
+    from thermompnn_amd._lib import TmpnnRangeError
+    from thermompnn_amd.engine import Engine
+    W = {k: v.clone() for k, v in synthetic_weights.items()}
+    W["prot_mpnn.features.edge_embedding.weight"] = W["prot_mpnn.features.edge_embedding.weight"] * 1e6
+    p = packed_inputs(load_golden("syn_L32"))
+    args = (p["X"], p["S"], p["mask"], p["ridx"], p["cenc"], p["offsets"])
+    want = Engine(W, "cuda:0", 48, precision="bf16x3").ssm_forward(*args)["ddg"]
+    assert bool(torch.isfinite(want).all())
+    eng = Engine(W, "cuda:0", 48, precision="f16x2")
+    raw = eng.ssm_forward(*args, check_status=False, want_hidden=True)
+    assert not bool(torch.isfinite(raw["hidden"]).all())                     # the overflow is real: poisoned decoder states
+    # (the ddG values themselves may look finite — the head's ReLUs map NaN to 0, as IEEE max does — which is exactly why
+    #  the head kernel checks its INPUT and raises the device flag)
+    with pytest.raises(TmpnnRangeError, match="bf16x3"):
+        eng.check_last_status()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = eng.ssm_forward(*args)["ddg"]
+    assert torch.equal(got, want) and any("bf16x3" in str(w.message) for w in rec)
+    strict = Engine(W, "cuda:0", 48, precision="f16x2", retry_precision=None)
+    with pytest.raises(TmpnnRangeError):
+        strict.ssm_forward(*args)
+
+
+def test_max_len_is_guarded(engine):
+    """A max_len below the longest protein can no longer overrun the kNN kernel's LDS row: host offsets are checked in
+    Python, device offsets by the kernel (empty rows + TMPNN_STATUS_MAXLEN)."""
+    from thermompnn_amd._lib import TmpnnError
+    p = packed_inputs(load_golden("syn_L256"))
+    args = (p["X"], p["S"], p["mask"], p["ridx"], p["cenc"])
+    with pytest.raises(TmpnnError, match="max_len"):
+        engine.ssm_forward(*args, p["offsets"], max_len=100)                 # device-resident offsets: the kernel's guard
+    with pytest.raises(TmpnnError, match="smaller than the longest"):
+        engine.ssm_forward(*args, p["offsets"].cpu(), max_len=100)           # host offsets: checked before the launch
+    ok = engine.ssm_forward(*args, p["offsets"], max_len=300)["ddg"]
+    assert torch.equal(ok, engine.ssm_forward(*args, p["offsets"])["ddg"])
+
+
+def test_real_weights_2OCJ():
+    """The reference's published table for examples/2OCJ.pdb (real v_48_020 + ThermoMPNN weights). Skipped
+    unless TMPNN_REAL_WEIGHTS_DIR holds vanilla_model_weights/v_48_020.pt and thermoMPNN_default.pt."""
+    root = os.environ.get("TMPNN_REAL_WEIGHTS_DIR", "")
+    vanilla = os.path.join(root, "vanilla_model_weights", "v_48_020.pt")
+    ckpt = os.path.join(root, "thermoMPNN_default.pt")
+    if not (root and os.path.exists(vanilla) and os.path.exists(ckpt)):
+        pytest.skip("real weights not supplied (TMPNN_REAL_WEIGHTS_DIR)")
+    from thermompnn_amd import custom_inference
+    model = custom_inference.load_model(ckpt, root, None)
+    rows = custom_inference.ssm_rows(model, os.path.join(GOLDEN, "2OCJ.pdb"), "A")
+    want = np.load(os.path.join(GOLDEN, "2OCJ_A_realweights_ddg.npz"))["ddg"]
+    got = np.array([r["ddG_pred"] for r in rows], dtype=np.float64).reshape(194, 20)
+    np.testing.assert_allclose(got, want, atol=TOL_DDG, rtol=0)
+
+
+def test_benchmark_dataset_evaluation(tmp_path, synthetic_weights):
+    """ddgBenchDataset rows -> TransferModel (per protein, the reference's loop) and the batched
+    ssm_scan path -> metrics. Predictions equal the reference golden tables at the listed positions; both paths agree."""
+    from thermompnn_amd import custom_inference
+    from thermompnn_amd.datasets import ddgBenchDataset
+    from thermompnn_amd.metrics import get_metrics
+    from thermompnn_amd.thermompnn_benchmarking import run_prediction_batched, run_prediction_default
+    ds = ddgBenchDataset(None, GOLDEN, os.path.join(GOLDEN, "ddgbench_sample.csv"))
+    model = custom_inference.load_model(None, None, 0)
+    results, rows = run_prediction_default("ThermoMPNN", model, "sample", ds, [], keep_preds=True)
+    g = {"2OCJ": load_golden("2OCJ_A")["ddg"], "2OCJ_gap_chainA": load_golden("2OCJ_A_gap")["ddg"]}
+    assert len(rows) == 6 and results[0]["n"] == 6                       # Q100E has no measurement, A999G no residue
+    for r in rows:
+        want = g[r["pdb"]][r["position"], "ACDEFGHIKLMNPQRSTVWY".index(r["mutation"])]
+        assert abs(r["ddG_pred"] - want) <= TOL_DDG
+    met = get_metrics([r["ddG_pred"] for r in rows], [r["ddG_true"] for r in rows])
+    assert all(abs(results[0][f"ddG {k}"] - met[k]) < 1e-12 for k in ("r2", "mse", "rmse", "spearman", "pearson"))
+    batched = run_prediction_batched("ThermoMPNN", model.engine(), "sample", ds, [])
+    assert batched[0]["n"] == 6 and all(abs(batched[0][f"ddG {k}"] - results[0][f"ddG {k}"]) < 1e-5
+                                        for k in ("r2", "mse", "rmse", "spearman", "pearson"))
 
 
 def test_bench_contract_line():

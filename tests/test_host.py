@@ -193,3 +193,88 @@ def test_metrics_match_scipy():
     assert abs(m["spearman"] - stats.spearmanr(p[ok], t[ok])[0]) < 1e-12
     assert abs(m["rmse"] - np.sqrt(np.mean((p[ok] - t[ok]) ** 2))) < 1e-12
     assert abs(m["r2"] - (1 - ((p[ok] - t[ok]) ** 2).sum() / ((t[ok] - t[ok].mean()) ** 2).sum())) < 1e-12
+
+
+def test_ddgbench_dataset_alignment_and_signs():
+    """ddgBenchDataset counterpart (/root/reference/datasets.py:248-317): author residue numbers -> parsed positions through
+    resn_list, the gap contingency after a numbering gap, skipped rows, ddG = -DDG, None for an empty cell."""
+    from thermompnn_amd.datasets import ddgBenchDataset
+    ds = ddgBenchDataset(None, GOLDEN, os.path.join(GOLDEN, "ddgbench_sample.csv"))
+    assert len(ds) == 2 and ds.wt_names == ["2OCJA", "2OCJ_gap_chainAA"] and ds.wt_seqs["2OCJ"].startswith("SVPSQ")
+    pdb, muts = ds[0]
+    assert pdb[0]["seq"][0] == "S" and [(m.position, m.wildtype, m.mutation) for m in muts] == [
+        (0, "S", "A"), (7, "Y", "F"), (14, "R", "K"), (4, "Q", "E")]                     # A999G: number not in the structure
+    assert [None if m.ddG is None else round(float(m.ddG), 4) for m in muts] == [1.5, -0.7, -2.25, None]
+    assert muts[0].ddG.shape == (1,) and muts[0].pdb == "2OCJ"
+    pdb, muts = ds[1]
+    seq = pdb[0]["seq"]
+    assert seq[54:57] == "---" and len(pdb[0]["resn_list"]) == len(seq) - 3
+    # S106 sits before the numbering gap (direct hit); P153 / T155 sit behind it: resn_list points 3 short, the contingency
+    # adds the gap count (reference :296-305)
+    assert [(m.position, m.wildtype, m.mutation) for m in muts] == [(10, "S", "T"), (57, "P", "A"), (59, "T", "S")]
+    assert all(seq[m.position] == m.wildtype for m in muts)
+
+
+def test_fireprot_dataset_and_alignment_map(tmp_path):
+    """FireProtDataset counterpart (:167-245): split pickle, per-protein grouping, and the global-alignment contingency
+    for a pdb_sequence that does not line up with the parsed structure."""
+    import pickle
+    from types import SimpleNamespace
+    from thermompnn_amd.datasets import FireProtDataset, global_alignment_map
+    from thermompnn_amd.pdb_io import alt_parse_PDB
+    assert global_alignment_map("ACDEFG", "ACXDEG") == [0, 1, 3, 4, None, 5]
+    assert global_alignment_map("MKT", "KT") == [None, 0, 1]
+    seq = alt_parse_PDB(os.path.join(GOLDEN, "2OCJ.pdb"), None)[0]["seq"]
+    shifted = "MG" + seq                                      # a construct with two extra N-terminal residues
+    csv_path = tmp_path / "fireprot.csv"
+    with open(csv_path, "w") as fh:
+        fh.write("pdb_id_corrected,pdb_sequence,pdb_position,wild_type,mutation,ddG\n")
+        fh.write(f"2OCJ,{shifted},2,{seq[0]},A,1.25\n")      # position 2 of the construct = position 0 of the structure
+        fh.write(f"2OCJ,{shifted},9,{seq[7]},F,-0.5\n")
+        fh.write(f"2OCJ,{shifted},0,M,A,0.3\n")              # faces a gap in the alignment: dropped
+        fh.write(f"2OCJ,{shifted},5,{seq[3]},G,\n")          # no ddG: filtered at load time (dropna)
+    with open(tmp_path / "splits.pkl", "wb") as fh:
+        pickle.dump({"train": [], "val": [], "test": ["2OCJ"]}, fh)
+    cfg = SimpleNamespace(data_loc=SimpleNamespace(fireprot_csv=str(csv_path), fireprot_splits=str(tmp_path / "splits.pkl"),
+                                                   fireprot_pdbs=GOLDEN))
+    ds = FireProtDataset(cfg, "test")
+    assert len(ds) == 1 and len(FireProtDataset(cfg, "all")) == 1 and len(FireProtDataset(cfg, "train")) == 0
+    pdb, muts = ds[0]
+    assert [(m.position, m.wildtype, m.mutation, round(float(m.ddG), 3)) for m in muts] == [(0, seq[0], "A", 1.25), (7, seq[7], "F", -0.5)]
+
+
+def test_lightning_checkpoint_loader_drops_foreign_keys(tmp_path):
+    """load_thermompnn_checkpoint on a Lightning-shaped file: optimizer state, hyper-parameters and Lightning-level
+    buffers are dropped, the 'model.' prefix stripped, and the result loads STRICTLY into TransferModel's tree. Files
+    that need the pickle loader are refused unless explicitly allowed."""
+    import collections
+    from thermompnn_amd import weights
+    sd = weights.synthetic_state_dict(0)
+    ckpt = {"epoch": 3, "global_step": 10, "pytorch-lightning_version": "1.9", "hyper_parameters": {"lr": 1e-3},
+            "optimizer_states": [{"state": {0: {"exp_avg": torch.zeros(3)}}}],
+            "state_dict": collections.OrderedDict([("model." + k, v) for k, v in sd.items()] +
+                                                  [("metrics.ddG.r2.sum_error", torch.zeros(1)), ("val_loss", torch.ones(1))])}
+    path = tmp_path / "lightning.ckpt"
+    torch.save(ckpt, path)
+    out = weights.load_thermompnn_checkpoint(str(path))
+    assert list(out.keys()) == list(sd.keys()) and all(torch.equal(out[k], sd[k]) for k in sd)
+
+    class Evil:                                               # anything that is not a plain tensor container
+        def __reduce__(self):
+            return (print, ("side effect",))
+    bad = tmp_path / "pickled.ckpt"
+    torch.save({"state_dict": ckpt["state_dict"], "hyper_parameters": Evil()}, bad)
+    with pytest.raises(RuntimeError, match="allow_pickle"):
+        weights.load_thermompnn_checkpoint(str(bad))
+    assert list(weights.load_thermompnn_checkpoint(str(bad), allow_pickle=True).keys()) == list(sd.keys())
+
+
+def test_published_real_weight_table_fixture():
+    """tests/golden/2OCJ_A_realweights_ddg.npz = the reference's published examples/ThermoMPNN_inference_2OCJ.csv as a
+    [194, 20] table (consumed by the skipped-unless-weights GPU test): shape, wild-type zeros and the survey's summary
+    statistics (mean 1.03, range -1.85 ... 4.76)."""
+    t = np.load(os.path.join(GOLDEN, "2OCJ_A_realweights_ddg.npz"))["ddg"]
+    g = np.load(os.path.join(GOLDEN, "2OCJ_A.npz"))
+    assert t.shape == (194, 20) and t.dtype == np.float32
+    assert (t[np.arange(194), g["S"].astype(int)] == 0).all()
+    assert abs(t.mean() - 1.03) < 0.01 and abs(t.min() + 1.85) < 0.01 and abs(t.max() - 4.76) < 0.01

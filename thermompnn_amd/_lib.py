@@ -29,9 +29,12 @@ SIGNATURES = {
     "tmpnn_tensor_name": (C.c_char_p, [_i]),
     "tmpnn_tensor_numel": (_i64, [_i]),
     "tmpnn_weights_packed_bytes": (_sz, []),
+    "tmpnn_status_error": (_i, [C.c_int32]),
     "tmpnn_weights_create": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _p, _sz, _p]),
+    "tmpnn_weights_create_p": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _p, _sz, C.c_char_p, _p]),
+    "tmpnn_weights_precision": (C.c_char_p, [_p]),
     "tmpnn_weights_destroy": (None, [_p]),
-    "tmpnn_knn_topk": (_i, [_p, _p, _p, _i, _i64, _i, _i, _p, _p, _p]),
+    "tmpnn_knn_topk": (_i, [_p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p]),
     "tmpnn_centrality": (_i, [_p, _p, _p, _i, _i64, C.c_float, _p, _p]),
     "tmpnn_edge_featurize": (_i, [_p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),
     "tmpnn_gather_nodes": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
@@ -42,25 +45,35 @@ SIGNATURES = {
     "tmpnn_enc_layer": (_i, [_p, _i, _p, _p, _p, _p, _i64, _p, _sz, _p]),
     "tmpnn_dec_layer": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _sz, _p]),
     "tmpnn_seq_embed": (_i, [_p, _p, _i64, _p, _p]),
-    "tmpnn_log_probs": (_i, [_p, _p, _i64, _p, _p]),
-    "tmpnn_ddg_head": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p]),
+    "tmpnn_log_probs": (_i, [_p, _p, _i64, _p, _p, _p]),
+    "tmpnn_ddg_head": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "tmpnn_pdb_parse": (_i, [C.c_char_p, C.c_char_p, C.POINTER(_p)]),
     "tmpnn_pdb_parse_batch": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _i, _i, C.POINTER(_p)]),
     "tmpnn_pdb_length": (_i64, [_p]),
     "tmpnn_pdb_num_chains": (_i, [_p]),
-    "tmpnn_pdb_fill": (_i, [_p, _p, _p, _p, _p, _p, C.c_char_p]),
+    "tmpnn_pdb_fill": (_i, [_p, _p, _p, _p, _p, _p, C.c_char_p, _p]),
     "tmpnn_pdb_free": (None, [_p]),
+    "tmpnn_ssm_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+}
+# include/tmpnn_debug.h: measurement / experiment hooks (bench.py's per-kernel timing, tools/); not the operator boundary
+DEBUG_SIGNATURES = {
     "tmpnn_profile_enable": (_i, [_i]),
+    "tmpnn_profile_fetch": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), _i]),
     "tmpnn_gemm_probe": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
     "tmpnn_clock_probe": (_i, [_i, _i, _p, _p, _p]),
     "tmpnn_ablate_enc_edge": (_i, [_p, _i, _p, _p, _p, _i64, _i, _p]),
-    "tmpnn_profile_fetch": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), _i]),
-    "tmpnn_ssm_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
 }
+PRECISIONS = ("f16x2", "bf16x3", "fp32")
+STATUS_RANGE, STATUS_MAXLEN = 1, 2
+E_RANGE = -5
 
 
 class TmpnnError(RuntimeError):
     pass
+
+
+class TmpnnRangeError(TmpnnError):
+    """TMPNN_E_RANGE: a result left the finite range (fp16 overflow of the f16x2 matrix-core path)."""
 
 
 _lib = None
@@ -83,7 +96,7 @@ def load(path: str | None = None):
         lib = C.CDLL(path)
     except OSError as e:
         raise TmpnnError(f"cannot load {path}: {e}") from e
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
@@ -97,7 +110,8 @@ def load(path: str | None = None):
 def check(rc: int, what: str = "") -> None:
     if rc != OK:
         msg = load().tmpnn_last_error()
-        raise TmpnnError(f"{what or 'tmpnn call'} failed with code {rc}: {msg.decode() if msg else ''}")
+        cls = TmpnnRangeError if rc == E_RANGE else TmpnnError
+        raise cls(f"{what or 'tmpnn call'} failed with code {rc}: {msg.decode() if msg else ''}")
 
 
 def tensor_names():

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "tmpnn_internal.h"
+#include "../../include/tmpnn_debug.h"
 
 // ---- errors ---------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -82,35 +83,51 @@ extern "C" int tmpnn_profile_fetch(const char **names, double *total_ms, int64_t
     g_prof.clear();
     return n;
 }
-int tm_num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
+int tm_num_cus() {           // of the CURRENT device (cached per device: one process may drive several GPUs)
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev] = n;
     }
-    return n;
+    return cache[dev];
 }
 
 // Matrix-core path of the per-edge GEMMs (featurizer, message and edge-update kernels), see tmpnn_split.h:
 //   "f16x2" (default) three-term fp16 split products, "bf16x3" six-term bf16 split products (both on the 16-bit matrix
 //   cores with fp32 accumulation, fp32-class accuracy), "fp32" = v_mfma_f32_16x16x4_f32. All pass the same parity tests.
-int tm_matmul_mode() {
-    static const int v = [] {
-        const char *e = getenv("TMPNN_PRECISION");
-        if (e == nullptr || e[0] == 0 || strcmp(e, "f16x2") == 0) return (int)TM_MM_F16X2;
-        if (strcmp(e, "bf16x3") == 0) return (int)TM_MM_BF16X3;
-        if (strcmp(e, "fp32") == 0) return (int)TM_MM_FP32;
-        fprintf(stderr, "tmpnn: unknown TMPNN_PRECISION '%s' (f16x2 | bf16x3 | fp32)\n", e);
-        abort();
-        return (int)TM_MM_F16X2;
-    }();
+static int parse_mode(const char *e) {      // -1 = unknown
+    if (e == nullptr || e[0] == 0 || strcmp(e, "f16x2") == 0) return (int)TM_MM_F16X2;
+    if (strcmp(e, "bf16x3") == 0) return (int)TM_MM_BF16X3;
+    if (strcmp(e, "fp32") == 0) return (int)TM_MM_FP32;
+    return -1;
+}
+static const char *mode_name(int m) { return m == TM_MM_F16X2 ? "f16x2" : m == TM_MM_BF16X3 ? "bf16x3" : "fp32"; }
+static int default_mode() {                  // TMPNN_PRECISION, read once; an unknown value is reported by weights_create
+    static const int v = parse_mode(getenv("TMPNN_PRECISION"));
     return v;
 }
-extern "C" const char *tmpnn_matmul_mode(void) {
-    const int m = tm_matmul_mode();
-    return m == TM_MM_F16X2 ? "f16x2" : m == TM_MM_BF16X3 ? "bf16x3" : "fp32";
+static thread_local int g_mode = -1;         // mode of the API call in progress (TmModeScope), -1 = none
+int tm_matmul_mode() {
+    if (g_mode >= 0) return g_mode;
+    const int d = default_mode();
+    return d < 0 ? (int)TM_MM_F16X2 : d;
+}
+TmModeScope::TmModeScope(int mode) : saved(g_mode) { g_mode = mode; }
+TmModeScope::~TmModeScope() { g_mode = saved; }
+extern "C" const char *tmpnn_matmul_mode(void) { return mode_name(tm_matmul_mode()); }
+extern "C" const char *tmpnn_weights_precision(const tmpnn_weights_t *w) { return w ? mode_name(w->mode) : nullptr; }
+
+extern "C" int tmpnn_status_error(int32_t status) {
+    if (status == 0) return TMPNN_OK;
+    if (status & TMPNN_STATUS_MAXLEN)
+        return tm_set_error(TMPNN_E_INVALID, "a protein is longer than the max_len passed to the call (its neighbour rows were left empty)");
+    if (status & TMPNN_STATUS_RANGE)
+        return tm_set_error(TMPNN_E_RANGE, "non-finite ddG / log-probability: an operand left the fp16 range of the f16x2 "
+                                           "matrix-core path (|x| >= 65504); use precision \"bf16x3\" (full fp32 range)");
+    return tm_set_error(TMPNN_E_INVALID, "unknown status bits 0x%x", (unsigned)status);
 }
 
 extern "C" int tmpnn_version(void) { return TMPNN_VERSION; }
@@ -180,7 +197,16 @@ extern "C" size_t tmpnn_weights_packed_bytes(void) {
 
 extern "C" int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *tensors, int n_tensors, void *packed,
                                     size_t packed_bytes, tmpnn_stream_t stream) {
+    return tmpnn_weights_create_p(out, tensors, n_tensors, packed, packed_bytes, nullptr, stream);
+}
+
+extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const *tensors, int n_tensors, void *packed,
+                                      size_t packed_bytes, const char *precision, tmpnn_stream_t stream) {
     if (!out || !tensors || !packed) return tm_set_error(TMPNN_E_INVALID, "weights_create: null argument");
+    const int mode = precision ? parse_mode(precision) : default_mode();
+    if (mode < 0)
+        return tm_set_error(TMPNN_E_INVALID, "weights_create: unknown precision '%s' (f16x2 | bf16x3 | fp32)",
+                            precision ? precision : getenv("TMPNN_PRECISION"));
     if (tensor_table().size() != TMPNN_N_TENSORS) return tm_set_error(TMPNN_E_INVALID, "internal tensor table size");
     if (n_tensors != TMPNN_N_MPNN_TENSORS && n_tensors != TMPNN_N_TENSORS)
         return tm_set_error(TMPNN_E_INVALID, "weights_create: n_tensors must be %d or %d, got %d", TMPNN_N_MPNN_TENSORS,
@@ -197,6 +223,7 @@ extern "C" int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *t
     if (!w) return tm_set_error(TMPNN_E_INVALID, "weights_create: host allocation failed");
     memset(w, 0, sizeof(*w));
     w->n_tensors = n_tensors;
+    w->mode = mode;
     std::map<std::string, const float *> by_name;
     for (int i = 0; i < n_tensors; ++i) { w->t[i] = tensors[i]; by_name[tensor_table()[i].name] = tensors[i]; }
     auto get = [&](const std::string &n) -> const float * {
@@ -350,14 +377,14 @@ static int run_dec_layer(const tmpnn_weights *w, int l, const float *hV_in, floa
 
 // ---- entry points ---------------------------------------------------------------------------------
 extern "C" int tmpnn_knn_topk(const float *X, const float *mask, const int32_t *offsets, int n_proteins, int64_t T,
-                              int max_len, int K, int32_t *E_idx, float *D_nb, tmpnn_stream_t stream) {
+                              int max_len, int K, int32_t *E_idx, float *D_nb, int32_t *status_opt, tmpnn_stream_t stream) {
     REQUIRE(X && mask && offsets && E_idx && D_nb, "knn_topk: null pointer");
     REQUIRE(n_proteins >= 0 && T >= 0 && T <= T_MAX, "knn_topk: bad sizes (N=%d, T=%lld)", n_proteins, (long long)T);
     REQUIRE(K >= 1 && K <= TMPNN_KS, "knn_topk: K=%d outside [1, %d]", K, TMPNN_KS);
     if (T == 0 || n_proteins == 0) return TMPNN_OK;
     REQUIRE(max_len >= 1, "knn_topk: max_len must be >= 1");
     if (max_len > 8192) return tm_set_error(TMPNN_E_UNSUPPORTED, "knn_topk: max_len %d > 8192", max_len);
-    return launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, (hipStream_t)stream);
+    return launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, status_opt, (hipStream_t)stream);
 }
 
 extern "C" int tmpnn_centrality(const float *X, const float *mask, const int32_t *offsets, int n_proteins, int64_t T,
@@ -374,6 +401,7 @@ extern "C" int tmpnn_edge_featurize(const tmpnn_weights_t *w, const float *X, co
     REQUIRE(w && X && residue_idx && chain_enc && E_idx && D_nb && h_E, "edge_featurize: null pointer");
     REQUIRE(T >= 0 && T <= T_MAX, "edge_featurize: bad T");
     if (T == 0) return TMPNN_OK;
+    const TmModeScope scope(w->mode);
     return launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, h_E, E_opt, (hipStream_t)stream);
 }
 
@@ -408,6 +436,7 @@ extern "C" int tmpnn_enc_layer(const tmpnn_weights_t *w, int layer, float *h_V, 
     REQUIRE(layer >= 0 && layer < 3, "enc_layer: layer %d outside [0,3)", layer);
     REQUIRE(T >= 0 && T <= T_MAX, "enc_layer: bad T");
     if (T == 0) return TMPNN_OK;
+    const TmModeScope scope(w->mode);
     LayerWs ws;
     TRY(carve_layer_ws(workspace, workspace_bytes, T, &ws));
     return run_enc_layer(w, layer, h_V, h_E, E_idx, mask, T, ws, false, nullptr, (hipStream_t)stream);
@@ -417,6 +446,7 @@ extern "C" int tmpnn_enc_layer(const tmpnn_weights_t *w, int layer, float *h_V, 
 extern "C" int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const float *P, float *h_E, const int32_t *E_idx,
                                      int64_t T, int ablation, tmpnn_stream_t stream) {
     REQUIRE(w && P && h_E && E_idx && layer >= 0 && layer < 3 && T > 0 && T <= T_MAX, "ablate_enc_edge: bad argument");
+    const TmModeScope scope(w->mode);
     return launch_enc_edge(w->enc[layer], P, h_E, E_idx, T, (hipStream_t)stream, ablation);
 }
 
@@ -439,6 +469,7 @@ extern "C" int tmpnn_dec_layer(const tmpnn_weights_t *w, int layer, const float 
     REQUIRE(layer >= 0 && layer < 3, "dec_layer: layer %d outside [0,3)", layer);
     REQUIRE(T >= 0 && T <= T_MAX, "dec_layer: bad T");
     if (T == 0) return TMPNN_OK;
+    const TmModeScope scope(w->mode);
     LayerWs ws;
     TRY(carve_layer_ws(workspace, workspace_bytes, T, &ws));
     return run_dec_layer(w, layer, h_V_in, h_V_out, h_E, E_idx, S, mask, T, ws, false, nullptr, (hipStream_t)stream);
@@ -451,25 +482,26 @@ extern "C" int tmpnn_seq_embed(const tmpnn_weights_t *w, const int32_t *S, int64
 }
 
 extern "C" int tmpnn_log_probs(const tmpnn_weights_t *w, const float *h_V, int64_t T, float *log_probs,
-                               tmpnn_stream_t stream) {
+                               int32_t *status_opt, tmpnn_stream_t stream) {
     REQUIRE(w && h_V && log_probs && T >= 0 && T <= T_MAX, "log_probs: bad argument");
     if (T == 0) return TMPNN_OK;
-    return launch_log_probs(w, h_V, T, log_probs, (hipStream_t)stream);
+    return launch_log_probs(w, h_V, T, log_probs, status_opt, (hipStream_t)stream);
 }
 
 extern "C" int tmpnn_ddg_head(const tmpnn_weights_t *w, const float *hV_last, const float *hV_prev, const int32_t *S,
-                              int64_t T, float *ddg, float *z_opt, tmpnn_stream_t stream) {
+                              int64_t T, float *ddg, float *z_opt, int32_t *status_opt, tmpnn_stream_t stream) {
     REQUIRE(w && hV_last && hV_prev && S && ddg && T >= 0 && T <= T_MAX, "ddg_head: bad argument");
     REQUIRE(w->n_tensors == TMPNN_N_TENSORS, "ddg_head: weight handle was created without the TransferModel head tensors");
     if (T == 0) return TMPNN_OK;
-    return launch_head(w, hV_last, hV_prev, S, T, ddg, z_opt, (hipStream_t)stream);
+    const TmModeScope scope(w->mode);
+    return launch_head(w, hV_last, hV_prev, S, T, ddg, z_opt, status_opt, (hipStream_t)stream);
 }
 
 extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const int32_t *S, const float *mask,
                                  const int32_t *residue_idx, const int32_t *chain_enc, const int32_t *offsets,
                                  int n_proteins, int64_t T, int max_len, int K, float *ddg, float *hidden_opt,
-                                 float *log_probs_opt, int32_t *E_idx_opt, void *workspace, size_t workspace_bytes,
-                                 tmpnn_stream_t stream) {
+                                 float *log_probs_opt, int32_t *E_idx_opt, int32_t *status_opt, void *workspace,
+                                 size_t workspace_bytes, tmpnn_stream_t stream) {
     REQUIRE(w, "ssm_forward: null weight handle");
     REQUIRE(n_proteins >= 0 && T >= 0 && T <= T_MAX, "ssm_forward: bad sizes");
     REQUIRE(K >= 1 && K <= TMPNN_KS, "ssm_forward: K=%d outside [1, %d]", K, TMPNN_KS);
@@ -477,8 +509,12 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     if (T == 0 || n_proteins == 0) return TMPNN_OK;   // an empty batch is a no-op (pointers may be null)
     REQUIRE(X && S && mask && residue_idx && chain_enc && offsets, "ssm_forward: null input pointer");
     REQUIRE(ddg || hidden_opt || log_probs_opt, "ssm_forward: no output requested");
+    REQUIRE(max_len >= 1, "ssm_forward: max_len must be >= 1 (the longest protein of the batch)");
     if (max_len > 8192) return tm_set_error(TMPNN_E_UNSUPPORTED, "ssm_forward: max_len %d > 8192", max_len);
     hipStream_t st = (hipStream_t)stream;
+    const TmModeScope scope(w->mode);
+    if (status_opt && hipMemsetAsync(status_opt, 0, sizeof(int32_t), st) != hipSuccess)
+        return tm_set_error(TMPNN_E_LAUNCH, "ssm_forward: status memset failed");
 
     LayerWs ws;
     Carver c{nullptr, 0};
@@ -493,7 +529,7 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     if (E_idx_opt) E_idx = E_idx_opt;
     if (hidden_opt) for (int l = 0; l < 3; ++l) hV[1 + l] = hidden_opt + (size_t)l * T * TMPNN_HID;
 
-    TRY(launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, st));
+    TRY(launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, status_opt, st));
     TRY(launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, hE, nullptr, st));
     if (hipMemsetAsync(hV[0], 0, (size_t)T * TMPNN_HID * 4, st) != hipSuccess)          // h_V starts at zero (:1228)
         return tm_set_error(TMPNN_E_LAUNCH, "ssm_forward: memset failed");
@@ -507,7 +543,7 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
         const NodeProj next = dec_msg_proj(w, l < 2 ? l + 1 : 2, ws.P, S);
         TRY(run_dec_layer(w, l, hV[l], hV[l + 1], hE, E_idx, S, mask, T, ws, true, l < 2 ? &next : nullptr, st));
     }
-    if (ddg) TRY(launch_head(w, hV[3], hV[2], S, T, ddg, nullptr, st));
-    if (log_probs_opt) TRY(launch_log_probs(w, hV[3], T, log_probs_opt, st));
+    if (ddg) TRY(launch_head(w, hV[3], hV[2], S, T, ddg, nullptr, status_opt, st));
+    if (log_probs_opt) TRY(launch_log_probs(w, hV[3], T, log_probs_opt, status_opt, st));
     return TMPNN_OK;
 }

@@ -99,7 +99,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // gelu(x) = max(x, 0) - u h(u),  u = min(|x|, 4 sqrt2),  h(u) = 0.5 erfc(u / sqrt2) = exp2(u B(u) - 1): B = the degree-8 fit above
 // with the 1/sqrt2 folded into its coefficients (tools/fit_gelu.py; max abs error 2.4e-7 in emulated fp32, the rounding
 // floor of x Phi(x)). Per value: v_min (|x| as a source modifier), 9 Horner steps + 1 (packed two values at a time),
-// v_exp, v_max and one fma with a negated source. For |x| > 4 sqrt2 the clamped u also stands in for |x| in the product: u h(u) < 4.4e-8 there.
+// v_exp, v_max and one fma with a negated |x| source. The product uses |x| itself, not the clamped u: a NaN / inf input
+// must come out as NaN (v_min / v_max return their finite operand, so u and max(x, 0) alone would turn a poisoned
+// value into a finite one and hide an fp16 overflow of the f16x2 path); for 4 sqrt2 < |x| < 50 that costs < 4e-7.
 #ifndef TM_GELU_ASM
 #define TM_GELU_ASM 1
 #endif
@@ -130,7 +132,7 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
     const f2 e = pk_horner(q, t, -1.0f);
     // the library is built with -mno-amdgpu-ieee -fno-honor-nans: fminf / fmaxf are single v_min / v_max (no canonicalising
     // v_max x, x in front of each)
-    return f2{fmaf(-t.x, __builtin_amdgcn_exp2f(e.x), fmaxf(x.x, 0.f)), fmaf(-t.y, __builtin_amdgcn_exp2f(e.y), fmaxf(x.y, 0.f))};
+    return f2{fmaf(-fabsf(x.x), __builtin_amdgcn_exp2f(e.x), fmaxf(x.x, 0.f)), fmaf(-fabsf(x.y), __builtin_amdgcn_exp2f(e.y), fmaxf(x.y, 0.f))};
 }
 __device__ __forceinline__ f4 gelu4(f4 v) {
     const f2 a = gelu2(f2{v.x, v.y}), b = gelu2(f2{v.z, v.w});

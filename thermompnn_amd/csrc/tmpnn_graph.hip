@@ -135,7 +135,8 @@ __device__ __forceinline__ void knn_row(float *d, const float *__restrict__ X, c
 
 __global__ __launch_bounds__(TM_THREADS, 8) void knn_kernel(const float *__restrict__ X, const float *__restrict__ mask,
                                                             const int32_t *__restrict__ offsets, int N, int T, int max_len,
-                                                            int K, int32_t *__restrict__ E_idx, float *__restrict__ D_nb) {
+                                                            int K, int32_t *__restrict__ E_idx, float *__restrict__ D_nb,
+                                                            int32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) float knn_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float *d = knn_lds + (size_t)wv * (max_len + (max_len >> 6) + 1);
@@ -147,6 +148,11 @@ __global__ __launch_bounds__(TM_THREADS, 8) void knn_kernel(const float *__restr
             if (offsets[mid] <= i) lo = mid; else hi = mid;
         }
         const int s = offsets[lo], L = offsets[lo + 1] - s;
+        if (L > max_len) {      // the caller's max_len sized this wavefront's LDS row: a longer protein would overrun it
+            if (lane < TM_KS) { E_idx[(size_t)i * TM_KS + lane] = -1; D_nb[(size_t)i * TM_KS + lane] = 0.f; }
+            if (lane == 0 && status) atomicOr(status, TMPNN_STATUS_MAXLEN);
+            continue;
+        }
         const int Keff = K < L ? K : L;
         if (L > 512) knn_row<true>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
         else knn_row<false>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
@@ -597,17 +603,15 @@ int launch_centrality(const float *X, const float *mask, const int32_t *offsets,
 }
 
 int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,
-               int32_t *E_idx, float *D_nb, hipStream_t st) {
+               int32_t *E_idx, float *D_nb, int32_t *status, hipStream_t st) {
     const size_t lds = (size_t)4 * (max_len + (max_len >> 6) + 1) * sizeof(float);   // knn_slot padding
     if (lds > 160 * 1024) return tm_set_error(TMPNN_E_UNSUPPORTED, "knn_topk: max_len %d needs %zu B of LDS", max_len, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // per call, not cached: the attribute is per device and one process may drive several GPUs
+    if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     const int64_t blocks = (T + 3) / 4;
     const int64_t cap = (int64_t)tm_num_cus() * 8;
-    { tm_prof_begin("knn", st); knn_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb); tm_prof_end(st); }
+    { tm_prof_begin("knn", st); knn_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status); tm_prof_end(st); }
     return tm_check_launch("knn_topk");
 }
 

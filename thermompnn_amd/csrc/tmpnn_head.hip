@@ -20,6 +20,7 @@ struct HeadArgs {
     const int32_t *S;
     float *ddg, *z_opt;
     int T;
+    int32_t *status;                      // may be null: TMPNN_STATUS_RANGE is OR-ed in when a ddG is not finite
 };
 
 __device__ __forceinline__ f4 relu4(f4 v) { return f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
@@ -39,6 +40,13 @@ __global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
         if (tid < ROWS) s_S[tid] = tid < rows ? a.S[r0 + tid] : 0;
         load_tile<NRB>(tX[0], a.hA + (size_t)r0 * TM_H, rows, tid);
         load_tile<NRB>(tX[1], a.hB + (size_t)r0 * TM_H, rows, tid);
+        if (a.status) {     // the ReLUs of both_out map NaN to 0: a poisoned decoder state must be flagged at the input
+            bool bad = false;
+            const unsigned *ua = reinterpret_cast<const unsigned *>(a.hA), *ub = reinterpret_cast<const unsigned *>(a.hB);
+            for (int k = tid; k < rows * TM_H; k += TM_THREADS)
+                bad |= tm_nonfinite_bits(ua[(size_t)r0 * TM_H + k]) || tm_nonfinite_bits(ub[(size_t)r0 * TM_H + k]);
+            if (bad) atomicOr(a.status, TMPNN_STATUS_RANGE);
+        }
 #pragma unroll
         for (int it = 0; it < 2 * NRB; ++it) {  // x[256:384] = W_s[S]
             const int idx = it * TM_THREADS + tid, row = idx >> 5, c = idx & 31;
@@ -119,7 +127,9 @@ __global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
             const float z = tX[2][chunk_off(row, aa >> 2) + (aa & 3)];
             const int wt = s_S[row];
             const float zw = tX[2][chunk_off(row, wt >> 2) + (wt & 3)];
-            a.ddg[(size_t)(r0 + row) * TMPNN_VOCAB + aa] = (dw * z + db) - (dw * zw + db);   // :110-116
+            const float dd = (dw * z + db) - (dw * zw + db);   // :110-116
+            a.ddg[(size_t)(r0 + row) * TMPNN_VOCAB + aa] = dd;
+            if (a.status && tm_nonfinite(dd)) atomicOr(a.status, TMPNN_STATUS_RANGE);
             if (a.z_opt) a.z_opt[(size_t)(r0 + row) * TMPNN_VOCAB + aa] = z;
         }
         __syncthreads();
@@ -181,9 +191,19 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
         for (int idx = tid; idx < ROWS * 32; idx += 512) {      // x = [h_last | h_prev | W_s[S]] -> planes
             const int row = idx >> 5, c = idx & 31;
             const bool ok = row < rows;
-            const f4 z = f4{0.f, 0.f, 0.f, 0.f};
-            store_split<SP, ROWS>(pX[0], row, c, ok ? ld4(a.hA + (size_t)(r0 + row) * TM_H + 4 * c) : z);
-            store_split<SP, ROWS>(pX[1], row, c, ok ? ld4(a.hB + (size_t)(r0 + row) * TM_H + 4 * c) : z);
+            // the ReLUs of both_out map NaN to 0, so a poisoned decoder state would come out as a finite ddG: flag it here, on
+            // the raw bits as loaded (see tm_nonfinite_bits)
+            typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+            const uv4 zero4 = uv4{0u, 0u, 0u, 0u};
+            const uv4 ra = ok ? *reinterpret_cast<const uv4 *>(a.hA + (size_t)(r0 + row) * TM_H + 4 * c) : zero4;
+            const uv4 rb = ok ? *reinterpret_cast<const uv4 *>(a.hB + (size_t)(r0 + row) * TM_H + 4 * c) : zero4;
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad = bad || tm_nonfinite_bits(ra[k]) || tm_nonfinite_bits(rb[k]);
+            if (a.status && bad) atomicOr(a.status, TMPNN_STATUS_RANGE);
+            const f4 va = __builtin_bit_cast(f4, ra), vb = __builtin_bit_cast(f4, rb);
+            store_split<SP, ROWS>(pX[0], row, c, va);
+            store_split<SP, ROWS>(pX[1], row, c, vb);
             store_split<SP, ROWS>(pX[2], row, c, ld4(a.Ws + (ok ? a.S[r0 + row] : 0) * TM_H + 4 * c));
         }
         __syncthreads();
@@ -261,7 +281,9 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
             const float z = tF2[chunk_off(row, aa >> 2) + (aa & 3)];
             const int wt = s_S[row];
             const float zw = tF2[chunk_off(row, wt >> 2) + (wt & 3)];
-            a.ddg[(size_t)(r0 + row) * TMPNN_VOCAB + aa] = (dw * z + db) - (dw * zw + db);   // :110-116
+            const float dd = (dw * z + db) - (dw * zw + db);   // :110-116
+            a.ddg[(size_t)(r0 + row) * TMPNN_VOCAB + aa] = dd;
+            if (a.status && tm_nonfinite(dd)) atomicOr(a.status, TMPNN_STATUS_RANGE);
             if (a.z_opt) a.z_opt[(size_t)(r0 + row) * TMPNN_VOCAB + aa] = z;
         }
         __syncthreads();
@@ -271,10 +293,14 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
 // log_softmax(W_out h + b): one wavefront per residue, lane a < 21 owns logit a.
 __global__ __launch_bounds__(TM_THREADS) void log_probs_kernel(const float *__restrict__ W, const float *__restrict__ b,
                                                                const float *__restrict__ h, int T,
-                                                               float *__restrict__ out) {
+                                                               float *__restrict__ out, int32_t *__restrict__ status) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int t = blockIdx.x * 4 + wv; t < T; t += gridDim.x * 4) {
         float logit = -INFINITY;
+        if (status) {      // poisoned input row -> flag (raw-bit test on the loaded values, see tm_nonfinite_bits)
+            const unsigned *ur = reinterpret_cast<const unsigned *>(h + (size_t)t * TM_H);
+            if (tm_nonfinite_bits(ur[lane]) || tm_nonfinite_bits(ur[lane + 64])) atomicOr(status, TMPNN_STATUS_RANGE);
+        }
         if (lane < TMPNN_VOCAB) {
             const float *wr = W + lane * TM_H, *hr = h + (size_t)t * TM_H;
             float s = 0.f;
@@ -288,7 +314,11 @@ __global__ __launch_bounds__(TM_THREADS) void log_probs_kernel(const float *__re
         float e = lane < TMPNN_VOCAB ? expf(logit - mx) : 0.f;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off);
-        if (lane < TMPNN_VOCAB) out[(size_t)t * TMPNN_VOCAB + lane] = (logit - mx) - logf(e);
+        if (lane < TMPNN_VOCAB) {
+            const float lp = (logit - mx) - logf(e);
+            out[(size_t)t * TMPNN_VOCAB + lane] = lp;
+            if (status && tm_nonfinite(lp)) atomicOr(status, TMPNN_STATUS_RANGE);
+        }
     }
 }
 
@@ -332,9 +362,9 @@ int launch_prep_tables(tmpnn_weights *w, hipStream_t st) {
 }
 
 int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg,
-                float *z_opt, hipStream_t st) {
+                float *z_opt, int32_t *status, hipStream_t st) {
     HeadArgs a{w->conv_center, w->conv_b, w->mlp_w[0], w->mlp_b[0], w->mlp_w[1], w->mlp_b[1], w->mlp_w[2], w->mlp_b[2],
-               w->ddg_w, w->ddg_b, w->Ws_w, hA, hB, S, ddg, z_opt, (int)T};
+               w->ddg_w, w->ddg_b, w->Ws_w, hA, hB, S, ddg, z_opt, (int)T, status};
     // tile height for load balance, as in node_update: 1 workgroup per CU, ~1.2 MB of weights streamed per tile
     const int64_t slots = tm_num_cus();
     int best_rows = 48;
@@ -362,9 +392,9 @@ int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const 
     return tm_check_launch("ddg_head");
 }
 
-int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, hipStream_t st) {
+int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, int32_t *status, hipStream_t st) {
     const int64_t blocks = (T + 3) / 4, cap = (int64_t)tm_num_cus() * 8;
-    { tm_prof_begin("log_probs", st); log_probs_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Wout_w, w->Wout_b, h, (int)T, out); tm_prof_end(st); }
+    { tm_prof_begin("log_probs", st); log_probs_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Wout_w, w->Wout_b, h, (int)T, out, status); tm_prof_end(st); }
     return tm_check_launch("log_probs");
 }
 

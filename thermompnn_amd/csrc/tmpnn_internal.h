@@ -18,6 +18,7 @@ struct DecW {
 };
 struct tmpnn_weights {
     int n_tensors;
+    int mode;              // TM_MM_*: matrix-core path of this handle's per-edge GEMMs
     const float *t[TMPNN_N_TENSORS];
     // features
     const float *pos_w, *pos_b, *edge_w, *norm_edges_w, *norm_edges_b, *We_w, *We_b, *Ws_w;
@@ -47,7 +48,7 @@ void tm_prof_end(hipStream_t st);
 
 // tmpnn_graph.hip
 int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,
-               int32_t *E_idx, float *D_nb, hipStream_t st);
+               int32_t *E_idx, float *D_nb, int32_t *status, hipStream_t st);
 int launch_centrality(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, float radius,
                       int32_t *out, hipStream_t st);
 int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx, const int32_t *cenc,
@@ -81,8 +82,8 @@ int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_i
 
 // tmpnn_head.hip
 int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg,
-                float *z_opt, hipStream_t st);
-int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, hipStream_t st);
+                float *z_opt, int32_t *status, hipStream_t st);
+int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, int32_t *status, hipStream_t st);
 int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float *hS, hipStream_t st);
 int launch_prep_tables(tmpnn_weights *w, hipStream_t st);
 
@@ -100,6 +101,18 @@ int launch_msg_wt(bool dec, const float *W1e, int ld1, const float *W2, const fl
 int launch_enc_edge_wt(const EncW &e, const char *W13l, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
 
 int tm_num_cus();
-// TMPNN_PRECISION = f16x2 (default) | bf16x3 | fp32: matrix-core path of the per-edge GEMMs (tmpnn_split.h)
+// matrix-core path of the per-edge GEMMs (tmpnn_split.h): a property of the weight handle (tmpnn_weights_create_p);
+// TMPNN_PRECISION = f16x2 (default) | bf16x3 | fp32 only picks the default of handles created without one.
 enum { TM_MM_FP32 = 0, TM_MM_BF16X3 = 1, TM_MM_F16X2 = 2 };
-int tm_matmul_mode();
+int tm_matmul_mode();                 // mode of the API call in progress on this thread (set from the handle)
+struct TmModeScope {                  // entry points that take a handle open one of these
+    int saved;
+    explicit TmModeScope(int mode);
+    ~TmModeScope();
+};
+// Non-finite tests under -fno-honor-nans. The kernels are built with relaxed NaN semantics, so hipcc may fold a NaN test
+// on the RESULT of floating-point arithmetic (measured: both the sum test and the exponent-bit test on a computed value
+// were compiled away; only the inf half survives). Tests are therefore made on raw bits LOADED FROM MEMORY, before any
+// arithmetic touches them: tm_nonfinite_bits on integer loads of the same addresses.
+__device__ __forceinline__ bool tm_nonfinite_bits(unsigned b) { return (b & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ bool tm_nonfinite(float x) { return tm_nonfinite_bits(__float_as_uint(x)); }   // inf only is guaranteed

@@ -210,12 +210,15 @@ extern "C" int64_t tmpnn_pdb_length(const tmpnn_pdb_t *p) { return p ? (int64_t)
 extern "C" int tmpnn_pdb_num_chains(const tmpnn_pdb_t *p) { return p ? p->n_chains : -1; }
 
 extern "C" int tmpnn_pdb_fill(const tmpnn_pdb_t *p, float *X, int32_t *S, float *mask, int32_t *residue_idx,
-                              int32_t *chain_enc, char *seq) {
+                              int32_t *chain_enc, char *seq, float *ca_mask) {
     if (!p) return tm_set_error(TMPNN_E_INVALID, "pdb_fill: null handle");
     const size_t L = p->S.size();
     if (X) for (size_t i = 0; i < L * 12; ++i) X[i] = std::isnan(p->X[i]) ? 0.f : p->X[i];
     if (S) memcpy(S, p->S.data(), L * sizeof(int32_t));
     if (mask) memcpy(mask, p->mask.data(), L * sizeof(float));
+    if (ca_mask)        // compute_centrality masks on the CA atom only (thermompnn_benchmarking.py:20-27)
+        for (size_t i = 0; i < L; ++i)
+            ca_mask[i] = (std::isnan(p->X[i * 12 + 3]) || std::isnan(p->X[i * 12 + 4]) || std::isnan(p->X[i * 12 + 5])) ? 0.f : 1.f;
     if (residue_idx) memcpy(residue_idx, p->ridx.data(), L * sizeof(int32_t));
     if (chain_enc) memcpy(chain_enc, p->cenc.data(), L * sizeof(int32_t));
     if (seq) { memcpy(seq, p->seq.data(), L); seq[L] = '\0'; }

@@ -367,15 +367,20 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
 }
 
 // Wave-owns-tile forms (tmpnn_wt.hip) for batches that give every wavefront of the chip work; the workgroup-per-tile
-// forms below stay the small-batch (latency) path. TMPNN_WT=0 disables them, TMPNN_WT_MIN_T moves the switch-over.
-static bool use_wt(int64_t T) {
-    static const int on = [] { const char *e = getenv("TMPNN_WT"); return e ? atoi(e) : 1; }();
+// forms below are the shipped path. Measured on MI355X (64 x L=256): message pass 0.221-0.225 ms against 0.230-0.234 ms,
+// edge update 0.42 vs 0.345 ms (its third weight does not fit LDS). A 4 % gain on one kernel family does not pay for
+// results that depend on the batch size in the last bits (the two forms round differently, and the choice would follow
+// T), so they are OPT-IN experiments: TMPNN_WT=1 enables the message kernels, TMPNN_WT_EDGE=1 the edge kernel as well,
+// TMPNN_WT_MIN_T moves the switch-over. DESIGN.md §7 has the ablation data.
+static bool use_wt(int64_t T, bool edge) {
+    static const int on = [] { const char *e = getenv("TMPNN_WT"); return e ? atoi(e) : 0; }();
+    static const int on_edge = [] { const char *e = getenv("TMPNN_WT_EDGE"); return e ? atoi(e) : 0; }();
     static const int64_t min_t = [] { const char *e = getenv("TMPNN_WT_MIN_T"); return e ? atoll(e) : 2048; }();
-    return on != 0 && T >= min_t;
+    return on != 0 && (!edge || on_edge != 0) && T >= min_t;
 }
 
 int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
-    if (mode == TM_MM_F16X2 && use_wt(T)) return launch_enc_edge_wt(e, e.W13l, P, hE, E_idx, T, st);
+    if (mode == TM_MM_F16X2 && use_wt(T, true)) return launch_enc_edge_wt(e, e.W13l, P, hE, E_idx, T, st);
     EdgeArgsB a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
@@ -823,7 +828,7 @@ __global__ __launch_bounds__(256, 2) void msg4_rp_kernel(MsgArgsB a) {
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                      const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt,
                      hipStream_t st) {
-    if (mode == TM_MM_F16X2 && use_wt(T)) return launch_msg_wt(dec, W1e, ld1, W2, b2, P, hE, E_idx, mask, T, Ssum, cnt, st);
+    if (mode == TM_MM_F16X2 && use_wt(T, false)) return launch_msg_wt(dec, W1e, ld1, W2, b2, P, hE, E_idx, mask, T, Ssum, cnt, st);
     MsgArgsB a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);

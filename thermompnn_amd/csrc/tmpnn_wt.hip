@@ -74,11 +74,19 @@ __device__ __forceinline__ void wt_put4(XFrag &x, f4 v) {
 #define WT_FENCE() __builtin_amdgcn_sched_barrier(0)
 // Loop-invariant small operands (biases, LayerNorm parameters) are re-read from L1 every tile: laundering the pointer
 // once per tile keeps LICM from hoisting 100+ VGPRs worth of them out of the tile loop.
-template <typename T>
-__device__ __forceinline__ const T *wt_launder(const T *p) {
+// (The result is typed as a GLOBAL pointer: a laundered generic pointer would turn every access into flat_load, which
+// ticks lgkmcnt as well and makes hipcc wait with vmcnt(0) — draining every prefetch in flight.)
+typedef const __attribute__((address_space(1))) float *gfloat_p;
+typedef const __attribute__((address_space(1))) char *gchar_p;
+__device__ __forceinline__ gfloat_p wt_launder(const float *p) {
     asm volatile("" : "+s"(p));
-    return p;
+    return (gfloat_p)p;
 }
+__device__ __forceinline__ gchar_p wt_launder(const char *p) {
+    asm volatile("" : "+s"(p));
+    return (gchar_p)p;
+}
+__device__ __forceinline__ f4 ld4g(gfloat_p p) { return *reinterpret_cast<const __attribute__((address_space(1))) f4 *>(p); }
 // WT_ABL: timing ablations (results are then meaningless): 1 no GELU, 2 no MFMA, 4 no node-term gathers, 8 no e-tile loads
 #ifndef WT_ABL
 #define WT_ABL 0
@@ -142,17 +150,39 @@ __device__ __forceinline__ u4 wt_frag(const FragBase &b, int p, int f) {
 // fetch_l(step) (LDS, or the L2 stream of the edge kernel's third GEMM), step = 4 cb + c
 template <int NR, typename FetchL>
 __device__ __forceinline__ void wt_gemm_cb(const FragBase &fb, int ph, FetchL &&fetch_l, int cb, const XFrag (&X)[NR][4], f4 (&acc)[NR]) {
+#ifndef WT_TWO_ACC
+#define WT_TWO_ACC 0
+#endif
+#if WT_TWO_ACC
+    f4 lo[NR];      // the two residual-plane terms accumulate here: consecutive MFMAs never share an accumulator
+#pragma unroll
+    for (int rb = 0; rb < NR; ++rb) lo[rb] = f4{0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const u4 ah = wt_frag(fb, ph, cb * 4 + c);
         const u4 al = fetch_l(cb * 4 + c);
+#if WT_TWO_ACC
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb) lo[rb] = WT_MFMA(al, X[rb][c].h, lo[rb]);
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb) acc[rb] = WT_MFMA(ah, X[rb][c].h, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb) lo[rb] = WT_MFMA(ah, X[rb][c].l, lo[rb]);
+#else
+        // one accumulator: with two column blocks per scheduling region the compiler alternates their MFMA chains
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb) acc[rb] = WT_MFMA(al, X[rb][c].h, acc[rb]);
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb) acc[rb] = WT_MFMA(ah, X[rb][c].l, acc[rb]);
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb) acc[rb] = WT_MFMA(ah, X[rb][c].h, acc[rb]);
+#endif
     }
+#if WT_TWO_ACC
+#pragma unroll
+    for (int rb = 0; rb < NR; ++rb) acc[rb] += lo[rb];
+#endif
 }
 
 #ifndef WT_PIPE
@@ -162,24 +192,37 @@ __device__ __forceinline__ void wt_gemm_cb(const FragBase &fb, int ph, FetchL &&
 // terms), epi(cb, acc) consumes the finished block (GELU, split into the next GEMM's B fragments, ...). WT_PIPE: the
 // epilogue of block cb - 1 sits in the same scheduling region as the MFMAs of block cb, so hipcc interleaves the VALU
 // work of one block with the matrix work of the next inside the wavefront (on top of the overlap with the SIMD partner).
+#ifndef WT_CBG
+#define WT_CBG 2       // column blocks per scheduling region: 2 blocks = 4 independent GELU chains beside 24 MFMAs (16-row passes)
+#endif
 template <int NR, typename FetchL, typename Init, typename Epi>
 __device__ __forceinline__ void wt_gemm8(const FragBase &fb, int ph, FetchL &&fetch_l, const XFrag (&X)[NR][4], Init &&init, Epi &&epi) {
-    f4 prev[NR];
+    constexpr int G = NR == 1 ? WT_CBG : 1, NG = 8 / G;
+    f4 prev[G][NR];
 #pragma unroll
-    for (int cb = 0; cb < 8 + WT_PIPE; ++cb) {
-        f4 acc[NR];
-        if (cb < 8) {
-            init(cb, acc);
-            wt_gemm_cb<NR>(fb, ph, fetch_l, cb, X, acc);
+    for (int g = 0; g < NG + WT_PIPE; ++g) {
+        f4 acc[G][NR];
+        if (g < NG) {
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                init(g * G + k, acc[k]);
+                wt_gemm_cb<NR>(fb, ph, fetch_l, g * G + k, X, acc[k]);
+            }
         }
         if (WT_PIPE) {
-            if (cb > 0) epi(cb - 1, prev);
-            if (cb < 8) {
+            if (g > 0) {
 #pragma unroll
-                for (int rb = 0; rb < NR; ++rb) prev[rb] = acc[rb];
+                for (int k = 0; k < G; ++k) epi((g - 1) * G + k, prev[k]);
+            }
+            if (g < NG) {
+#pragma unroll
+                for (int k = 0; k < G; ++k)
+#pragma unroll
+                    for (int rb = 0; rb < NR; ++rb) prev[k][rb] = acc[k][rb];
             }
         } else {
-            epi(cb, acc);
+#pragma unroll
+            for (int k = 0; k < G; ++k) epi(g * G + k, acc[k]);
         }
         WT_FENCE();
     }
@@ -233,83 +276,16 @@ struct MsgArgsW {
     int T;
 };
 
-// rows [r0, r0 + 16 NR) of residue i: tot[cb] += sum_rows ma * gelu(W2 gelu(pre) + b2)
-template <int NR, bool DEC>
-__device__ __forceinline__ void msg_wt_pass(const MsgArgsW &a, const char *sW, int i, int r0, int lane, f4 (&tot)[8], float &cnt) {
-    WT_FENCE();
-    const int m = lane & 15, q = lane >> 4;
-    const FragBase fb = wt_frag_base(sW, lane);
-    const float *b2 = wt_launder(a.b2);
-    const float mi = a.mask[i];
-    int jj[NR];
-    float ma[NR];
-#pragma unroll
-    for (int rb = 0; rb < NR; ++rb) {
-        const int j0 = a.E_idx[(size_t)i * TM_KS + r0 + 16 * rb + m];
-        jj[rb] = j0 < 0 ? i : j0;
-        ma[rb] = j0 < 0 ? 0.f : (DEC ? 1.f : mi * a.mask[jj[rb]]);
-        cnt += ma[rb];
-    }
-    XFrag X[NR][4], Y[NR][4];
-    {   // all loads of the pass in flight together (one HBM round trip), then the conversions
-        f4 raw[NR][8];
-#pragma unroll
-        for (int rb = 0; rb < NR; ++rb) {
-            const float *src = a.hE + ((size_t)i * TM_KS + r0 + 16 * rb + m) * TM_H + 8 * q;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { raw[rb][2 * c] = wt_ld_tile(src + 32 * c, lane); raw[rb][2 * c + 1] = wt_ld_tile(src + 32 * c + 4, lane); }
-        }
-        WT_FENCE();
-#pragma unroll
-        for (int rb = 0; rb < NR; ++rb)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) X[rb][c] = wt_split8(raw[rb][2 * c], raw[rb][2 * c + 1]);
-        WT_FENCE();
-    }
-    // GEMM 1 (+ gathered node terms riding in the accumulator) -> GELU -> Y planes
-    {
-        f4 g0 = wt_ld_gather(a.P + (size_t)i * 256 + wt_col(0, q), lane), gj[NR], g0_of[2];
-#pragma unroll
-        for (int rb = 0; rb < NR; ++rb) gj[rb] = wt_ld_gather(a.P + (size_t)jj[rb] * 256 + 128 + wt_col(0, q), lane);
-        wt_gemm8<NR>(fb, 0, [&](int st) { return wt_frag(fb, 1, st); }, X,
-            [&](int cb, f4 (&acc)[NR]) {
-                g0_of[cb & 1] = g0;
-#pragma unroll
-                for (int rb = 0; rb < NR; ++rb) acc[rb] = DEC ? gj[rb] : g0 + gj[rb];
-                if (cb < 7) {                           // node terms of the next block: in flight under this block's MFMAs
-                    g0 = wt_ld_gather(a.P + (size_t)i * 256 + wt_col(cb + 1, q), lane);
-#pragma unroll
-                    for (int rb = 0; rb < NR; ++rb) gj[rb] = wt_ld_gather(a.P + (size_t)jj[rb] * 256 + 128 + wt_col(cb + 1, q), lane);
-                }
-            },
-            [&](int cb, const f4 (&acc)[NR]) {
-#pragma unroll
-                for (int rb = 0; rb < NR; ++rb) {
-                    f4 v = acc[rb];
-                    if (DEC) v = g0_of[cb & 1] + mi * v;
-                    if (cb & 1) wt_put4<1>(Y[rb][cb >> 1], WT_GELU4(v));
-                    else wt_put4<0>(Y[rb][cb >> 1], WT_GELU4(v));
-                }
-            });
-    }
-    // GEMM 2 -> GELU -> masked sum over the rows
-    wt_gemm8<NR>(fb, 2, [&](int st) { return wt_frag(fb, 3, st); }, Y,
-        [&](int cb, f4 (&acc)[NR]) {
-            const f4 bias = ld4(b2 + wt_col(cb, q));
-#pragma unroll
-            for (int rb = 0; rb < NR; ++rb) acc[rb] = bias;
-        },
-        [&](int cb, const f4 (&acc)[NR]) {
-#pragma unroll
-            for (int rb = 0; rb < NR; ++rb) {
-                tot[cb] += WT_GELU4(acc[rb]) * ma[rb];   // slots without a neighbour: zero e row, finite node terms, ma = 0
-            }
-            touch(tot[cb]);
-        });
+// One wavefront walks its residues in passes of 16 rows (3 per residue). The loop is software-pipelined ACROSS passes:
+// the neighbour indices of pass p + 1 are requested before GEMM 1 of pass p, its e rows and gathered node terms
+// before GEMM 2 of pass p — every global load has a full GEMM (several microseconds) to land, so no wavefront ever sits
+// on an HBM / L2 round trip in front of its MFMAs (the first version of this kernel spent 38 % of its time there).
+struct WtPass { int i, r0; };
+__device__ __forceinline__ WtPass wt_next_pass(WtPass p, const TileRange &tr) {
+    return p.r0 < 32 ? WtPass{p.i, p.r0 + 16} : WtPass{p.i + tr.step, 0};
 }
 
-// NW wavefronts per workgroup (one workgroup per CU): 8 -> 2 per SIMD, row passes (32, 16); 12 / 16 -> 3 / 4 per SIMD,
-// three 16-row passes (the VGPR budget shrinks to 168 / 128, the VALU sees more independent instruction streams)
+// NW wavefronts per workgroup, one workgroup per CU: 8 -> 2 per SIMD (256 VGPRs), 12 -> 3 per SIMD (168 VGPRs)
 template <bool DEC, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void msg_wt_kernel(MsgArgsW a) {
     __shared__ __attribute__((aligned(16))) char sW[4 * WT_PLANE_BYTES];      // W1e.h | W1e.l | W2.h | W2.l
@@ -318,27 +294,109 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void msg_wt_kernel(MsgArgsW a) {
     wt_build_frags(a.W2, TM_H, sW + 2 * WT_PLANE_BYTES, sW + 3 * WT_PLANE_BYTES, tid, 64 * NW);
     __syncthreads();
     const TileRange tr = wt_wave_range<NW>(a.T, wv);
-    for (int i = tr.begin; i < tr.end; i += tr.step) {
-        f4 tot[8];
+    if (tr.begin >= tr.end) return;
+    const FragBase fb = wt_frag_base(sW, lane);
+
+    auto load_idx = [&](WtPass p) { return a.E_idx[(size_t)p.i * TM_KS + p.r0 + m]; };
+    auto row_ptr = [&](WtPass p) { return a.hE + ((size_t)p.i * TM_KS + p.r0 + m) * TM_H + 8 * q; };
+
+    // pipeline fill: pass 0 completely, index of pass 1
+    WtPass cur{tr.begin, 0};
+    XFrag X[1][4], Y[1][4];
+    f4 gj[8];
+    float ma;
+    {
+        const int j0 = load_idx(cur);
+        const int jj = j0 < 0 ? cur.i : j0;
+        ma = j0 < 0 ? 0.f : (DEC ? 1.f : a.mask[cur.i] * a.mask[jj]);
+        f4 raw[8];
+        const float *src = row_ptr(cur);
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb) tot[cb] = f4{0.f, 0.f, 0.f, 0.f};
-        float cnt = 0.f;
-        if (NW == 8) {
-            msg_wt_pass<2, DEC>(a, sW, i, 0, lane, tot, cnt);
-            msg_wt_pass<1, DEC>(a, sW, i, 32, lane, tot, cnt);
-        } else {
-#pragma unroll 1
-            for (int r0 = 0; r0 < TM_KS; r0 += 16) msg_wt_pass<1, DEC>(a, sW, i, r0, lane, tot, cnt);
+        for (int c = 0; c < 8; ++c) raw[c] = wt_ld_tile(src + 32 * (c >> 1) + 4 * (c & 1), lane);
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) gj[cb] = wt_ld_gather(a.P + (size_t)jj * 256 + 128 + wt_col(cb, q), lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) X[0][c] = wt_split8(raw[2 * c], raw[2 * c + 1]);
+    }
+    WtPass nxt = wt_next_pass(cur, tr);
+    bool has_next = nxt.i < tr.end;
+    int j0n = load_idx(has_next ? nxt : cur);
+    f4 tot[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) tot[cb] = f4{0.f, 0.f, 0.f, 0.f};
+    float cnt = 0.f;
+
+    while (true) {
+        WT_FENCE();
+        const gfloat_p b2 = wt_launder(a.b2);
+        const float *Pi = a.P + (size_t)cur.i * 256;
+        const float mi = a.mask[cur.i];
+        // ---- GEMM 1 (+ node terms riding in the accumulator) -> GELU -> Y planes ----
+        {
+            f4 g0 = wt_ld_gather(Pi + wt_col(0, q), lane), g0_of[8];
+            wt_gemm8<1>(fb, 0, [&](int st) { return wt_frag(fb, 1, st); }, X,
+                [&](int cb, f4 (&acc)[1]) {
+                    g0_of[cb] = g0;
+                    acc[0] = DEC ? gj[cb] : g0 + gj[cb];
+                    if (cb < 7) g0 = wt_ld_gather(Pi + wt_col(cb + 1, q), lane);     // own row: L1 / L2 hit, one block ahead
+                },
+                [&](int cb, const f4 (&acc)[1]) {
+                    f4 v = acc[0];
+                    if (DEC) v = g0_of[cb] + mi * v;
+                    if (cb & 1) wt_put4<1>(Y[0][cb >> 1], WT_GELU4(v));
+                    else wt_put4<0>(Y[0][cb >> 1], WT_GELU4(v));
+                });
         }
+        // ---- requests of the next pass (its index arrived during GEMM 1): e rows, gathered node terms, the index after ----
+        const WtPass ld = has_next ? nxt : cur;              // nothing left: re-read this pass (harmless), no divergent code
+        const int jjn = j0n < 0 ? ld.i : j0n;
+        const float mask_in = a.mask[ld.i], mask_jn = a.mask[jjn];       // unconditional: consumed after GEMM 2
+        // gfx9 retires loads in order (one vmcnt): GEMM 2's biases are requested BEFORE the prefetches so that waiting for a
+        // bias never waits for the e rows / node terms of the next pass
+        f4 bias[8];
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {
-            f4 t;
+        for (int cb = 0; cb < 8; ++cb) bias[cb] = ld4g(b2 + wt_col(cb, q));
+        f4 rawn[8], gjn[8];
+        {
+            const float *src = row_ptr(ld);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) t[k] = wt_row_scan(tot[cb][k]);
-            if (m == 15) st4(a.Ssum + (size_t)i * TM_H + wt_col(cb, q), t);
+            for (int c = 0; c < 8; ++c) rawn[c] = wt_ld_tile(src + 32 * (c >> 1) + 4 * (c & 1), lane);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) gjn[cb] = wt_ld_gather(a.P + (size_t)jjn * 256 + 128 + wt_col(cb, q), lane);
         }
-        cnt = wt_row_scan(cnt);
-        if (lane == 15) a.cnt[i] = cnt;
+        const WtPass nn = wt_next_pass(ld, tr);
+        const bool has_nn = has_next && nn.i < tr.end;
+        const int j0nn = load_idx(has_nn ? nn : ld);
+        WT_FENCE();
+        // ---- GEMM 2 -> GELU -> masked sum over the rows ----
+        wt_gemm8<1>(fb, 2, [&](int st) { return wt_frag(fb, 3, st); }, Y,
+            [&](int cb, f4 (&acc)[1]) { acc[0] = bias[cb]; },
+            [&](int cb, const f4 (&acc)[1]) {
+                tot[cb] += WT_GELU4(acc[0]) * ma;        // slots without a neighbour: zero e row, finite node terms, ma = 0
+                touch(tot[cb]);
+            });
+        cnt += ma;
+        if (cur.r0 == 32) {                                  // last pass of the residue: sum over the 16 rows of each quarter
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                f4 t;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = wt_row_scan(tot[cb][k]);
+                if (m == 15) st4(a.Ssum + (size_t)cur.i * TM_H + wt_col(cb, q), t);
+                tot[cb] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+            cnt = wt_row_scan(cnt);
+            if (lane == 15) a.cnt[cur.i] = cnt;
+            cnt = 0.f;
+        }
+        if (!has_next) break;
+        WT_FENCE();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) X[0][c] = wt_split8(rawn[2 * c], rawn[2 * c + 1]);
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) gj[cb] = gjn[cb];
+        ma = j0n < 0 ? 0.f : (DEC ? 1.f : mask_in * mask_jn);
+        cur = nxt; nxt = nn; has_next = has_nn; j0n = j0nn;
     }
 }
 
@@ -355,157 +413,146 @@ struct EdgeArgsW {
     int T;
 };
 
-template <int NR>
-__device__ __forceinline__ void edge_wt_pass(const EdgeArgsW &a, const char *sW, int i, int r0, int lane) {
-    WT_FENCE();
-    const int m = lane & 15, q = lane >> 4;
-    const FragBase fb = wt_frag_base(sW, lane);
-    const float *b12 = wt_launder(a.b12), *b13 = wt_launder(a.b13), *g3 = wt_launder(a.g3), *be3 = wt_launder(a.be3);
-    int jj[NR];
-    bool valid[NR];
-    float *rowp[NR];
-#pragma unroll
-    for (int rb = 0; rb < NR; ++rb) {
-        const int j0 = a.E_idx[(size_t)i * TM_KS + r0 + 16 * rb + m];
-        jj[rb] = j0 < 0 ? i : j0;
-        valid[rb] = j0 >= 0;
-        rowp[rb] = a.hE + ((size_t)i * TM_KS + r0 + 16 * rb + m) * TM_H;
-    }
-    XFrag X[NR][4], Y[NR][4];
-    {   // all loads of the pass in flight together (one HBM round trip), then the conversions
-        f4 raw[NR][8];
-#pragma unroll
-        for (int rb = 0; rb < NR; ++rb)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { raw[rb][2 * c] = ld4(rowp[rb] + 8 * q + 32 * c); raw[rb][2 * c + 1] = ld4(rowp[rb] + 8 * q + 32 * c + 4); }
-        WT_FENCE();
-#pragma unroll
-        for (int rb = 0; rb < NR; ++rb)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) X[rb][c] = wt_split8(raw[rb][2 * c], raw[rb][2 * c + 1]);
-        WT_FENCE();
-    }
-    // GEMM 1: W11e . e + (W11a h_i + b11) + W11c h_j
-    {
-        f4 g0 = wt_ld_gather(a.P + (size_t)i * 256 + wt_col(0, q), lane), gj[NR];
-#pragma unroll
-        for (int rb = 0; rb < NR; ++rb) gj[rb] = wt_ld_gather(a.P + (size_t)jj[rb] * 256 + 128 + wt_col(0, q), lane);
-        wt_gemm8<NR>(fb, 0, [&](int st) { return wt_frag(fb, 3, st); }, X,
-            [&](int cb, f4 (&acc)[NR]) {
-#pragma unroll
-                for (int rb = 0; rb < NR; ++rb) acc[rb] = g0 + gj[rb];
-                if (cb < 7) {
-                    g0 = wt_ld_gather(a.P + (size_t)i * 256 + wt_col(cb + 1, q), lane);
-#pragma unroll
-                    for (int rb = 0; rb < NR; ++rb) gj[rb] = wt_ld_gather(a.P + (size_t)jj[rb] * 256 + 128 + wt_col(cb + 1, q), lane);
-                }
-            },
-            [&](int cb, const f4 (&acc)[NR]) {
-#pragma unroll
-                for (int rb = 0; rb < NR; ++rb) {
-                    if (cb & 1) wt_put4<1>(Y[rb][cb >> 1], gelu4(acc[rb]));
-                    else wt_put4<0>(Y[rb][cb >> 1], gelu4(acc[rb]));
-                }
-            });
-    }
-    // GEMM 2 (its output planes reuse X)
-    wt_gemm8<NR>(fb, 1, [&](int st) { return wt_frag(fb, 4, st); }, Y,
-        [&](int cb, f4 (&acc)[NR]) {
-            const f4 bias = ld4(b12 + wt_col(cb, q));
-#pragma unroll
-            for (int rb = 0; rb < NR; ++rb) acc[rb] = bias;
-        },
-        [&](int cb, const f4 (&acc)[NR]) {
-#pragma unroll
-            for (int rb = 0; rb < NR; ++rb) {
-                if (cb & 1) wt_put4<1>(X[rb][cb >> 1], gelu4(acc[rb]));
-                else wt_put4<0>(X[rb][cb >> 1], gelu4(acc[rb]));
-            }
-        });
-    // GEMM 3 + residual; the l-plane fragments of W13 stream from L2 three k-steps ahead
-    f4 v[NR][8];
-    {
-        constexpr int D = 3;
-        // uniform base (SGPR) + 32-bit lane offset: the saddr form of global_load needs no per-fragment 64-bit VGPR address
-        const char *gl = wt_launder(a.W13l);
-        const unsigned lo16 = (unsigned)lane * 16u;
-        u4 alq[D];
-#pragma unroll
-        for (int st = 0; st < D; ++st) alq[st] = *reinterpret_cast<const u4 *>(gl + st * WT_FRAG_BYTES + lo16);
-        f4 res[NR], res_of[2][NR];
-#pragma unroll
-        for (int rb = 0; rb < NR; ++rb) res[rb] = ld4(rowp[rb] + wt_col(0, q));
-        wt_gemm8<NR>(fb, 2,
-            [&](int st) {
-                const u4 al = alq[st % D];
-                if (st + D < 32) alq[st % D] = *reinterpret_cast<const u4 *>(gl + (st + D) * WT_FRAG_BYTES + lo16);
-                return al;
-            },
-            X,
-            [&](int cb, f4 (&acc)[NR]) {
-                const f4 bias = ld4(b13 + wt_col(cb, q));
-#pragma unroll
-                for (int rb = 0; rb < NR; ++rb) { acc[rb] = bias; res_of[cb & 1][rb] = res[rb]; }
-                if (cb < 7) {
-#pragma unroll
-                    for (int rb = 0; rb < NR; ++rb) res[rb] = ld4(rowp[rb] + wt_col(cb + 1, q));
-                }
-            },
-            [&](int cb, const f4 (&acc)[NR]) {
-#pragma unroll
-                for (int rb = 0; rb < NR; ++rb) { v[rb][cb] = res_of[cb & 1][rb] + acc[rb]; touch(v[rb][cb]); }
-            });
-    }
-    // LayerNorm 3 (nn.LayerNorm: biased variance, eps 1e-5) over the 128 features of each row: 32 values in the lane,
-    // the other 96 in the lanes of the same m — two passes, as the reference does
-    float mean[NR], rstd[NR];
-#pragma unroll
-    for (int rb = 0; rb < NR; ++rb) {
-        f4 s4 = v[rb][0];
-#pragma unroll
-        for (int cb = 1; cb < 8; ++cb) s4 += v[rb][cb];
-        mean[rb] = wt_quad_sum((s4.x + s4.y) + (s4.z + s4.w)) * (1.0f / 128.0f);
-        f4 d4 = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {
-            const f4 d = v[rb][cb] - mean[rb];
-            d4 += d * d;
-        }
-        const float var = wt_quad_sum((d4.x + d4.y) + (d4.z + d4.w)) * (1.0f / 128.0f);
-        rstd[rb] = __builtin_amdgcn_rsqf(var + 1e-5f);
-    }
-    WT_FENCE();
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-        const int col = wt_col(cb, q);
-        const f4 g4 = ld4(g3 + col), b4 = ld4(be3 + col);
-#pragma unroll
-        for (int rb = 0; rb < NR; ++rb) {
-            const f4 y = (v[rb][cb] - mean[rb]) * rstd[rb] * g4 + b4;
-            // slots without a neighbour keep the zeros the featurizer wrote
-            st4(rowp[rb] + col, valid[rb] ? y : f4{0.f, 0.f, 0.f, 0.f});
-        }
-        WT_FENCE();
-    }
-}
-
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void enc_edge_wt_kernel(EdgeArgsW a) {
     __shared__ __attribute__((aligned(16))) char sW[5 * WT_PLANE_BYTES];      // W11e.h | W12.h | W13.h | W11e.l | W12.l
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     wt_build_frags(a.W11e, 384, sW, sW + 3 * WT_PLANE_BYTES, tid, 64 * NW);
     wt_build_frags(a.W12, TM_H, sW + WT_PLANE_BYTES, sW + 4 * WT_PLANE_BYTES, tid, 64 * NW);
     wt_build_frags(a.W13, TM_H, sW + 2 * WT_PLANE_BYTES, nullptr, tid, 64 * NW);
     __syncthreads();
     const TileRange tr = wt_wave_range<NW>(a.T, wv);
-    for (int i = tr.begin; i < tr.end; i += tr.step) {
-        if (NW == 8) {
-            edge_wt_pass<2>(a, sW, i, 0, lane);
-            edge_wt_pass<1>(a, sW, i, 32, lane);
-        } else {
-#pragma unroll 1
-            for (int r0 = 0; r0 < TM_KS; r0 += 16) edge_wt_pass<1>(a, sW, i, r0, lane);
+    if (tr.begin >= tr.end) return;
+    const FragBase fb = wt_frag_base(sW, lane);
+    const unsigned lo16 = (unsigned)lane * 16u;
+
+    auto load_idx = [&](WtPass p) { return a.E_idx[(size_t)p.i * TM_KS + p.r0 + m]; };
+    auto row_ptr = [&](WtPass p) { return a.hE + ((size_t)p.i * TM_KS + p.r0 + m) * TM_H; };
+
+    // pipeline fill: pass 0 completely, index of pass 1 (same cross-pass software pipeline as the message kernel)
+    WtPass cur{tr.begin, 0};
+    XFrag X[1][4], Y[1][4];
+    f4 gj[8];
+    bool valid;
+    {
+        const int j0 = load_idx(cur);
+        const int jj = j0 < 0 ? cur.i : j0;
+        valid = j0 >= 0;
+        f4 raw[8];
+        const float *src = row_ptr(cur) + 8 * q;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) raw[c] = ld4(src + 32 * (c >> 1) + 4 * (c & 1));
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) gj[cb] = wt_ld_gather(a.P + (size_t)jj * 256 + 128 + wt_col(cb, q), lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) X[0][c] = wt_split8(raw[2 * c], raw[2 * c + 1]);
+    }
+    WtPass nxt = wt_next_pass(cur, tr);
+    bool has_next = nxt.i < tr.end;
+    int j0n = load_idx(has_next ? nxt : cur);
+
+    while (true) {
+        WT_FENCE();
+        const gfloat_p b12 = wt_launder(a.b12), b13 = wt_launder(a.b13), g3 = wt_launder(a.g3), be3 = wt_launder(a.be3);
+        const gchar_p gl = wt_launder(a.W13l);
+        const float *Pi = a.P + (size_t)cur.i * 256;
+        float *rowp = row_ptr(cur);
+        // ---- GEMM 1: W11e . e + (W11a h_i + b11) + W11c h_j -> GELU -> Y ----
+        {
+            f4 g0 = wt_ld_gather(Pi + wt_col(0, q), lane);
+            wt_gemm8<1>(fb, 0, [&](int st) { return wt_frag(fb, 3, st); }, X,
+                [&](int cb, f4 (&acc)[1]) {
+                    acc[0] = g0 + gj[cb];
+                    if (cb < 7) g0 = wt_ld_gather(Pi + wt_col(cb + 1, q), lane);
+                },
+                [&](int cb, const f4 (&acc)[1]) {
+                    if (cb & 1) wt_put4<1>(Y[0][cb >> 1], WT_GELU4(acc[0]));
+                    else wt_put4<0>(Y[0][cb >> 1], WT_GELU4(acc[0]));
+                });
         }
+        // ---- requests of the next pass: e rows, gathered node terms, the index after ----
+        const WtPass ld = has_next ? nxt : cur;
+        const int jjn = j0n < 0 ? ld.i : j0n;
+        const bool validn = j0n >= 0;
+        f4 bias[8];          // GEMM 2's biases first (in-order vmcnt, see the message kernel)
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) bias[cb] = ld4g(b12 + wt_col(cb, q));
+        f4 rawn[8], gjn[8];
+        {
+            const float *src = row_ptr(ld) + 8 * q;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rawn[c] = ld4(src + 32 * (c >> 1) + 4 * (c & 1));
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) gjn[cb] = wt_ld_gather(a.P + (size_t)jjn * 256 + 128 + wt_col(cb, q), lane);
+        }
+        const WtPass nn = wt_next_pass(ld, tr);
+        const bool has_nn = has_next && nn.i < tr.end;
+        const int j0nn = load_idx(has_nn ? nn : ld);
+        WT_FENCE();
+        // ---- GEMM 2 -> GELU (its output planes reuse X) ----
+        wt_gemm8<1>(fb, 1, [&](int st) { return wt_frag(fb, 4, st); }, Y,
+            [&](int cb, f4 (&acc)[1]) { acc[0] = bias[cb]; },
+            [&](int cb, const f4 (&acc)[1]) {
+                if (cb & 1) wt_put4<1>(X[0][cb >> 1], WT_GELU4(acc[0]));
+                else wt_put4<0>(X[0][cb >> 1], WT_GELU4(acc[0]));
+            });
+        // ---- GEMM 3 + residual; the l-plane fragments of W13 stream from L2 three k-steps ahead ----
+        f4 v[8];
+        {
+            constexpr int D = 3;
+            u4 alq[D];
+#pragma unroll
+            for (int st = 0; st < D; ++st) alq[st] = *reinterpret_cast<const __attribute__((address_space(1))) u4 *>(gl + st * WT_FRAG_BYTES + lo16);
+            f4 res = ld4(rowp + wt_col(0, q)), res_of[8];
+            wt_gemm8<1>(fb, 2,
+                [&](int st) {
+                    const u4 al = alq[st % D];
+                    if (st + D < 32) alq[st % D] = *reinterpret_cast<const __attribute__((address_space(1))) u4 *>(gl + (st + D) * WT_FRAG_BYTES + lo16);
+                    return al;
+                },
+                X,
+                [&](int cb, f4 (&acc)[1]) {
+                    acc[0] = ld4g(b13 + wt_col(cb, q));
+                    res_of[cb] = res;
+                    if (cb < 7) res = ld4(rowp + wt_col(cb + 1, q));       // the fp32 residual: re-read from L2 one block ahead
+                },
+                [&](int cb, const f4 (&acc)[1]) {
+                    v[cb] = res_of[cb] + acc[0];
+                    touch(v[cb]);
+                });
+        }
+        // ---- LayerNorm 3 (nn.LayerNorm: biased variance, eps 1e-5) over the 128 features of the row: 32 values in this
+        // lane, the other 96 in the lanes of the same m — two passes, as the reference does ----
+        {
+            f4 s4 = v[0];
+#pragma unroll
+            for (int cb = 1; cb < 8; ++cb) s4 += v[cb];
+            const float mean = wt_quad_sum((s4.x + s4.y) + (s4.z + s4.w)) * (1.0f / 128.0f);
+            f4 d4 = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const f4 d = v[cb] - mean;
+                d4 += d * d;
+            }
+            const float var = wt_quad_sum((d4.x + d4.y) + (d4.z + d4.w)) * (1.0f / 128.0f);
+            const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+            WT_FENCE();
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const int col = wt_col(cb, q);
+                const f4 y = (v[cb] - mean) * rstd * ld4g(g3 + col) + ld4g(be3 + col);
+                // slots without a neighbour keep the zeros the featurizer wrote
+                st4(rowp + col, valid ? y : f4{0.f, 0.f, 0.f, 0.f});
+                if (cb & 1) WT_FENCE();
+            }
+        }
+        if (!has_next) break;
+        WT_FENCE();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) X[0][c] = wt_split8(rawn[2 * c], rawn[2 * c + 1]);
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) gj[cb] = gjn[cb];
+        valid = validn; cur = nxt; nxt = nn; has_next = has_nn; j0n = j0nn;
     }
 }
 
@@ -521,7 +568,7 @@ int launch_wt_prep(const float *W13, char *dst_lplane, hipStream_t st) {
 }
 
 static int wt_waves() {      // TMPNN_WT_WAVES = 8 | 12 | 16 wavefronts per workgroup
-    static const int nw = [] { const char *e = getenv("TMPNN_WT_WAVES"); const int v = e ? atoi(e) : 8; return v == 12 || v == 16 ? v : 8; }();
+    static const int nw = [] { const char *e = getenv("TMPNN_WT_WAVES"); const int v = e ? atoi(e) : 8; return v == 4 || v == 12 || v == 16 ? v : 8; }();
     return nw;
 }
 static int wt_grid(int64_t T, int nw) {
@@ -537,6 +584,7 @@ int launch_msg_wt(bool dec, const float *W1e, int ld1, const float *W2, const fl
     if (dec) msg_wt_kernel<true, NW><<<grid, 64 * NW, 0, st>>>(a);           \
     else msg_wt_kernel<false, NW><<<grid, 64 * NW, 0, st>>>(a)
     if (nw == 16) { WT_LAUNCH_MSG(16); }
+    else if (nw == 4) { WT_LAUNCH_MSG(4); }
     else if (nw == 12) { WT_LAUNCH_MSG(12); }
     else { WT_LAUNCH_MSG(8); }
 #undef WT_LAUNCH_MSG
@@ -547,6 +595,7 @@ int launch_enc_edge_wt(const EncW &e, const char *W13l, const float *P, float *h
     EdgeArgsW a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, W13l, hE, E_idx, (int)T};
     const int nw = wt_waves(), grid = wt_grid(T, nw);
     if (nw == 16) enc_edge_wt_kernel<16><<<grid, 1024, 0, st>>>(a);
+    else if (nw == 4) enc_edge_wt_kernel<4><<<grid, 256, 0, st>>>(a);
     else if (nw == 12) enc_edge_wt_kernel<12><<<grid, 768, 0, st>>>(a);
     else enc_edge_wt_kernel<8><<<grid, 512, 0, st>>>(a);
     return tm_check_launch("enc_edge_wt");

@@ -46,7 +46,8 @@ def pdb_id_of(path: str) -> str:
     return os.path.basename(path).rstrip(".pdb")
 
 
-def load_model(model_path: str | None, thermompnn_dir: str | None, synthetic_seed: int | None, device="cuda"):
+def load_model(model_path: str | None, thermompnn_dir: str | None, synthetic_seed: int | None, device="cuda",
+               precision: str | None = None):
     if synthetic_seed is not None:
         sd = _weights.synthetic_state_dict(synthetic_seed)
         tmp = tempfile.mkdtemp(prefix="tmpnn_w_")
@@ -59,6 +60,7 @@ def load_model(model_path: str | None, thermompnn_dir: str | None, synthetic_see
     cfg = AttrDict(model=AttrDict(MODEL_CFG), platform=AttrDict(thermompnn_dir=thermompnn_dir))
     model = TransferModel(cfg)
     model.load_state_dict(sd)
+    model.precision = precision
     return model.eval().to(device)
 
 
@@ -68,11 +70,8 @@ def ssm_rows(model, pdb_path: str, chain: str, model_name: str = "ThermoMPNN"):
     muts = mutation_objects(mut_pdb[0])
     with torch.no_grad():
         pred, _ = model(mut_pdb, muts)
-    vals = torch.cat([p["ddG"] for p in pred if p is not None]).cpu()              # one D2H copy
-    if not bool(torch.isfinite(vals).all()):
-        raise RuntimeError("non-finite ddG: the default f16x2 matrix-core path needs |activations| < 65504 — "
-                           "rerun with TMPNN_PRECISION=bf16x3 (full fp32 range)")
-    vals = vals.tolist()
+    # (range problems never get here: Engine.ssm_forward reruns an overflowing f16x2 batch in bf16x3 or raises)
+    vals = torch.cat([p["ddG"] for p in pred if p is not None]).cpu().tolist()     # one D2H copy
     rows, k = [], 0
     dataset = pdb_id_of(pdb_path)
     for m in muts:

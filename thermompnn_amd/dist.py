@@ -36,8 +36,15 @@ def all_gather_tables(local: torch.Tensor, rows_per_rank: Sequence[int], group=N
     C = local.shape[1]
     padded = local.new_zeros((max_rows, C))
     padded[: local.shape[0]] = local
-    out = local.new_empty((world * max_rows, C))
-    dist.all_gather_into_tensor(out, padded, group=group)
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        # a gloo group (CPU tests, the one-device smoke mode) exchanges host buffers; the real path is RCCL on device memory
+        host = padded.cpu()
+        out_h = host.new_empty((world * max_rows, C))
+        dist.all_gather_into_tensor(out_h, host, group=group)
+        out = out_h.to(local.device)
+    else:
+        out = local.new_empty((world * max_rows, C))
+        dist.all_gather_into_tensor(out, padded, group=group)
     return [out[r * max_rows: r * max_rows + rows_per_rank[r]] for r in range(world)]
 
 
@@ -86,14 +93,81 @@ def pack_proteins(proteins: Sequence[dict], ids: Sequence[int], device):
                 max_len=max(lens))
 
 
-def ssm_scan(engine, proteins: Sequence[dict], group=None, gather: bool = True):
-    """Full SSM of many proteins, sharded over the group's GPUs: -> list of [L_i, 21] ddG tables."""
+def ssm_scan(engine, proteins: Sequence[dict], group=None, gather: bool = True, centrality: bool = False,
+             chunk_residues: int = 1 << 18, radius: float = 10.0):
+    """Full SSM of many proteins, sharded over the group's GPUs (analysis/SSM.py:105-126 runs them one per forward).
+
+    Every rank runs the ragged pipeline on its LPT shard, in chunks of at most ``chunk_residues`` residues (the
+    workspace is ~27.5 KB per residue), then ONE padded all-gather exchanges the tables. With ``centrality`` the
+    neighbour count (#CA within ``radius``; compute_centrality, thermompnn_benchmarking.py:20-35, masked on the CA
+    atom) rides along as a 22nd column, so there is still a single collective.
+    -> list of [L_i, 21] ddG tables (device tensors) in the original order — or (tables, [L_i] int32 counts)."""
     lengths = [len(p["S"]) for p in proteins]
+    C = 22 if centrality else 21
 
     def compute(ids):
-        b = pack_proteins(proteins, ids, engine.device)
-        if not ids:
-            return torch.zeros((0, 21), dtype=torch.float32, device=engine.device)
-        return engine.ssm_forward(b["X"], b["S"], b["mask"], b["ridx"], b["cenc"], b["offsets"], max_len=b["max_len"])["ddg"]
+        local = torch.empty((sum(lengths[i] for i in ids), C), dtype=torch.float32, device=engine.device)
+        pos, k = 0, 0
+        while k < len(ids):
+            chunk, tot = [], 0
+            while k < len(ids) and (not chunk or tot + lengths[ids[k]] <= chunk_residues):
+                chunk.append(ids[k])
+                tot += lengths[ids[k]]
+                k += 1
+            b = pack_proteins(proteins, chunk, engine.device)
+            out = engine.ssm_forward(b["X"], b["S"], b["mask"], b["ridx"], b["cenc"], b["offsets"], max_len=b["max_len"])
+            local[pos:pos + tot, :21] = out["ddg"]
+            if centrality:
+                import numpy as np
+                ca = torch.as_tensor(np.concatenate([np.asarray(proteins[i].get("ca_mask", proteins[i]["mask"])) for i in chunk]))
+                local[pos:pos + tot, 21] = engine.centrality(b["X"], ca, b["offsets"], radius).to(torch.float32)
+            pos += tot
+        return local
 
-    return scan_sharded(lengths, compute, group, engine.K, gather)
+    tables = scan_sharded(lengths, compute, group, engine.K, gather)
+    if not centrality:
+        return tables
+    ddg = [None if t is None else t[:, :21] for t in tables]
+    cen = [None if t is None else t[:, 21].round().to(torch.int32) for t in tables]
+    return ddg, cen
+
+
+def select_mutations(tables: Sequence[torch.Tensor], triples) -> torch.Tensor:
+    """ddG of an explicit mutation list (BASELINE config 4: 200 k listed mutants over 300 proteins).
+    ``triples``: integer array [M, 3] of (protein index, 0-based position, amino-acid index into ALPHABET[:20]);
+    ``tables``: the per-protein [L_i, 21] tables of ``ssm_scan``. One gather on the device -> [M] float32."""
+    import numpy as np
+    tr = np.asarray(triples, dtype=np.int64).reshape(-1, 3)
+    if tr.shape[0] == 0:
+        return torch.zeros(0, dtype=torch.float32, device=tables[0].device if tables else "cpu")
+    lens = np.array([t.shape[0] for t in tables], dtype=np.int64)
+    if (tr[:, 0] < 0).any() or (tr[:, 0] >= len(tables)).any():
+        raise IndexError("mutation list names a protein outside the scanned set")
+    if (tr[:, 1] < 0).any() or (tr[:, 1] >= lens[tr[:, 0]]).any() or (tr[:, 2] < 0).any() or (tr[:, 2] >= 20).any():
+        raise IndexError("mutation list has a position / amino-acid index out of range")
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    flat = torch.cat([t.reshape(-1) for t in tables])
+    idx = torch.as_tensor((starts[tr[:, 0]] + tr[:, 1]) * tables[0].shape[1] + tr[:, 2], device=flat.device)
+    return flat[idx]
+
+
+def init_from_env(one_device: bool = False, backend: Optional[str] = None):
+    """Process-group set-up for a ``torchrun`` / ``python -m torch.distributed.run`` launch (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment): one process per GPU, backend "nccl" (= RCCL over xGMI on ROCm).
+    ``one_device`` (or TMPNN_ONE_DEVICE=1) puts every rank on cuda:0 with a gloo group — the N>1 code path on a 1-GPU
+    box. -> (rank, world, device); a plain single process gets (0, 1, cuda:0) and no group."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    one_device = one_device or os.environ.get("TMPNN_ONE_DEVICE") == "1"
+    index = 0 if one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", index)
+    torch.cuda.set_device(index)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or os.environ.get("TMPNN_DIST_BACKEND") or ("gloo" if one_device else "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return rank, world, device

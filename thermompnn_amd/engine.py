@@ -3,13 +3,14 @@ all arithmetic. Every method takes/returns torch CUDA tensors and launches on th
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
 
 from . import _lib
-from ._lib import HID, KS, VOCAB, TmpnnError, check
+from ._lib import HID, KS, VOCAB, TmpnnError, TmpnnRangeError, check
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -29,8 +30,14 @@ def _need_cuda(*ts):
 class Weights:
     """Device-resident weight set + the native handle (tmpnn_weights_create)."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device, with_head: Optional[bool] = None):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device, with_head: Optional[bool] = None,
+                 precision: Optional[str] = None, tensors: Optional[List[torch.Tensor]] = None):
+        """``precision``: "f16x2" | "bf16x3" | "fp32" (matrix-core path of every call through this handle) or None for
+        the library default. ``tensors``: device tensors of another Weights of the same model to share (a second
+        handle at another precision costs only its 0.8 MB of derived tables)."""
         lib = _lib.load()
+        if precision is not None and precision not in _lib.PRECISIONS:
+            raise TmpnnError(f"precision={precision!r}: expected one of {_lib.PRECISIONS}")
         device = torch.device(device)
         if device.type != "cuda":
             raise TmpnnError("weights must live on a CUDA (ROCm) device")
@@ -39,8 +46,8 @@ class Weights:
         if with_head is None:
             with_head = all(n in sd for n in names[_lib.N_MPNN_TENSORS:])
         n = _lib.N_TENSORS if with_head else _lib.N_MPNN_TENSORS
-        self.tensors: List[torch.Tensor] = []
-        for i, name in enumerate(names[:n]):
+        self.tensors: List[torch.Tensor] = list(tensors) if tensors is not None else []
+        for i, name in enumerate(names[:n] if tensors is None else []):
             key = name if i >= _lib.N_MPNN_TENSORS else ("prot_mpnn." + name if ("prot_mpnn." + name) in sd else name)
             if key not in sd:
                 raise KeyError(f"state dict lacks {key!r}")
@@ -56,8 +63,9 @@ class Weights:
         arr = (C.c_void_p * n)(*[t.data_ptr() for t in self.tensors])
         self.handle = C.c_void_p()
         with torch.cuda.device(device):
-            check(lib.tmpnn_weights_create(C.byref(self.handle), arr, n, _ptr(self.packed), self.packed.numel(), _stream()),
-                  "tmpnn_weights_create")
+            check(lib.tmpnn_weights_create_p(C.byref(self.handle), arr, n, _ptr(self.packed), self.packed.numel(),
+                                             precision.encode() if precision else None, _stream()), "tmpnn_weights_create_p")
+        self.precision = lib.tmpnn_weights_precision(self.handle).decode()
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -72,14 +80,52 @@ class Weights:
 class Engine:
     """One weight set on one GPU. All tensors are packed along the residue axis (T = sum of lengths)."""
 
-    def __init__(self, state_dict, device="cuda", k_neighbors: int = 48):
+    def __init__(self, state_dict, device="cuda", k_neighbors: int = 48, precision: Optional[str] = None,
+                 retry_precision: Optional[str] = "bf16x3"):
+        """``precision``: matrix-core path of the per-edge GEMMs ("f16x2" default | "bf16x3" | "fp32").
+        ``retry_precision``: when a forward in f16x2 leaves the finite range (an operand >= 65504 overflowed fp16), it is
+        rerun once at this precision with a warning (None: raise TmpnnRangeError instead)."""
         self.lib = _lib.load()
-        self.w = Weights(state_dict, device)
+        self.w = Weights(state_dict, device, precision=precision)
         self.device = self.w.device
+        self.precision = self.w.precision
+        self.retry_precision = retry_precision
         if not 1 <= int(k_neighbors) <= KS:
             raise TmpnnError(f"k_neighbors={k_neighbors} outside [1, {KS}]")
         self.K = int(k_neighbors)
         self._ws: Optional[torch.Tensor] = None
+        self._alt: Dict[str, Weights] = {self.precision: self.w}
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def weights_for(self, precision: str) -> Weights:
+        """The handle for ``precision`` (created on first use; shares the raw tensors)."""
+        if precision not in self._alt:
+            self._alt[precision] = Weights({}, self.device, with_head=self.w.with_head, precision=precision,
+                                           tensors=self.w.tensors)
+        return self._alt[precision]
+
+    def _raise_status(self, what: str) -> int:
+        """Reads the device status word (ONE 4-byte D2H copy = a stream sync) and raises on TMPNN_STATUS_MAXLEN;
+        returns the remaining bits (TMPNN_STATUS_RANGE is the caller's to handle)."""
+        st = int(self._status.item())
+        if st & _lib.STATUS_MAXLEN:
+            check(self.lib.tmpnn_status_error(_lib.STATUS_MAXLEN), what)
+        return st
+
+    @staticmethod
+    def _max_len(offsets, given: Optional[int]) -> int:
+        """Longest protein of the batch. Derived from ``offsets`` whenever that costs no device sync (host data);
+        a caller-supplied value is only trusted for device-resident offsets (the kernel still guards it and reports
+        TMPNN_STATUS_MAXLEN instead of overrunning its scratch)."""
+        if not (isinstance(offsets, torch.Tensor) and offsets.is_cuda):
+            o = np.asarray(offsets).astype(np.int64)
+            true_len = int((o[1:] - o[:-1]).max()) if o.size > 1 else 0
+            if given is not None and given < true_len:
+                raise TmpnnError(f"max_len={given} is smaller than the longest protein ({true_len})")
+            return max(true_len, 1) if given is None else int(given)
+        if given is not None:
+            return int(given)
+        return int((offsets[1:] - offsets[:-1]).max().item()) if offsets.numel() > 1 else 0
 
     # -- buffers ---------------------------------------------------------------------------------
     def _workspace(self, nbytes: int) -> torch.Tensor:
@@ -96,14 +142,15 @@ class Engine:
 
     # -- individual operators (parity tests drive these) --------------------------------------------
     def knn_topk(self, X, mask, offsets, max_len: Optional[int] = None):
+        max_len = self._max_len(offsets, max_len)
         X, mask, offsets = self._f32(X), self._f32(mask), self._i32(offsets)
         T, N = X.shape[0], offsets.numel() - 1
-        if max_len is None:
-            max_len = int((offsets[1:] - offsets[:-1]).max().item()) if N else 0
         E_idx = torch.empty((T, KS), dtype=torch.int32, device=self.device)
         D_nb = torch.empty((T, KS), dtype=torch.float32, device=self.device)
+        self._status.zero_()
         check(self.lib.tmpnn_knn_topk(_ptr(X), _ptr(mask), _ptr(offsets), N, T, max_len, self.K, _ptr(E_idx), _ptr(D_nb),
-                                      _stream()), "tmpnn_knn_topk")
+                                      _ptr(self._status), _stream()), "tmpnn_knn_topk")
+        self._raise_status("tmpnn_knn_topk")
         return E_idx, D_nb
 
     def centrality(self, X, mask, offsets, radius: float = 10.0):
@@ -145,7 +192,7 @@ class Engine:
 
     def log_probs(self, h_V):
         out = torch.empty((h_V.shape[0], VOCAB), dtype=torch.float32, device=self.device)
-        check(self.lib.tmpnn_log_probs(self.w.handle, _ptr(h_V), h_V.shape[0], _ptr(out), _stream()), "tmpnn_log_probs")
+        check(self.lib.tmpnn_log_probs(self.w.handle, _ptr(h_V), h_V.shape[0], _ptr(out), None, _stream()), "tmpnn_log_probs")
         return out
 
     def ddg_head(self, hV_last, hV_prev, S, want_z: bool = False):
@@ -154,7 +201,7 @@ class Engine:
         ddg = torch.empty((T, VOCAB), dtype=torch.float32, device=self.device)
         z = torch.empty_like(ddg) if want_z else None
         check(self.lib.tmpnn_ddg_head(self.w.handle, _ptr(hV_last), _ptr(hV_prev), _ptr(S), T, _ptr(ddg), _ptr(z),
-                                      _stream()), "tmpnn_ddg_head")
+                                      None, _stream()), "tmpnn_ddg_head")
         return (ddg, z) if want_z else ddg
 
     def gather_rows(self, nodes, idx_i32):
@@ -168,14 +215,21 @@ class Engine:
     # -- the fused path -----------------------------------------------------------------------------
     def ssm_forward(self, X, S, mask, residue_idx, chain_enc, offsets, max_len: Optional[int] = None,
                     want_ddg: bool = True, want_hidden: bool = False, want_log_probs: bool = False,
-                    want_E_idx: bool = False, out: Optional[dict] = None):
-        """Packed inputs ([T,4,3], [T], ...) -> dict(ddg [T,21], hidden [3,T,128], log_probs [T,21], E_idx [T,48])."""
+                    want_E_idx: bool = False, out: Optional[dict] = None, check_status: bool = True,
+                    precision: Optional[str] = None):
+        """Packed inputs ([T,4,3], [T], ...) -> dict(ddg [T,21], hidden [3,T,128], log_probs [T,21], E_idx [T,48]).
+
+        ``check_status`` (default) reads the 4-byte device status word after the launches — one stream sync — and
+          * raises if a protein is longer than ``max_len``,
+          * on a non-finite ddG / log-probability (fp16 overflow of the f16x2 path) reruns the batch once at
+            ``retry_precision`` with a warning, or raises TmpnnRangeError.
+        Throughput loops pass ``check_status=False`` (nothing syncs; call ``check_last_status()`` when convenient).
+        ``precision`` overrides the engine's precision for this call."""
+        max_len = self._max_len(offsets, max_len)
         X, mask = self._f32(X), self._f32(mask)
         S, ridx, cenc, offsets = self._i32(S), self._i32(residue_idx), self._i32(chain_enc), self._i32(offsets)
         _need_cuda(X, S, mask)
         T, N = X.shape[0], offsets.numel() - 1
-        if max_len is None:
-            max_len = int((offsets[1:] - offsets[:-1]).max().item()) if N else 0
         res = out if out is not None else {}
         dev = self.device
         if want_ddg and "ddg" not in res:
@@ -187,13 +241,57 @@ class Engine:
         if want_E_idx and "E_idx" not in res:
             res["E_idx"] = torch.empty((T, KS), dtype=torch.int32, device=dev)
         ws = self._workspace(self.lib.tmpnn_workspace_bytes(T))
-        check(self.lib.tmpnn_ssm_forward(self.w.handle, _ptr(X), _ptr(S), _ptr(mask), _ptr(ridx), _ptr(cenc), _ptr(offsets),
-                                         N, T, max_len, self.K, _ptr(res.get("ddg") if want_ddg else None),
-                                         _ptr(res.get("hidden") if want_hidden else None),
-                                         _ptr(res.get("log_probs") if want_log_probs else None),
-                                         _ptr(res.get("E_idx") if want_E_idx else None), _ptr(ws), ws.numel(), _stream()),
-              "tmpnn_ssm_forward")
+
+        def run(w: Weights):
+            check(self.lib.tmpnn_ssm_forward(w.handle, _ptr(X), _ptr(S), _ptr(mask), _ptr(ridx), _ptr(cenc), _ptr(offsets),
+                                             N, T, max_len, self.K, _ptr(res.get("ddg") if want_ddg else None),
+                                             _ptr(res.get("hidden") if want_hidden else None),
+                                             _ptr(res.get("log_probs") if want_log_probs else None),
+                                             _ptr(res.get("E_idx") if want_E_idx else None), _ptr(self._status), _ptr(ws),
+                                             ws.numel(), _stream()), "tmpnn_ssm_forward")
+
+        used = precision or self.precision
+        run(self.weights_for(used))
+        if check_status and T > 0 and N > 0:
+            st = self._raise_status("tmpnn_ssm_forward")
+            if st & _lib.STATUS_RANGE:
+                retry = self.retry_precision
+                if used != "f16x2" or not retry or retry == used:
+                    check(self.lib.tmpnn_status_error(st), f"tmpnn_ssm_forward[{used}]")
+                warnings.warn(f"ThermoMPNN HIP engine: non-finite result in {used} (an operand left the fp16 range); "
+                              f"rerunning this batch at precision {retry}", RuntimeWarning, stacklevel=2)
+                run(self.weights_for(retry))
+                st = self._raise_status("tmpnn_ssm_forward")
+                if st:
+                    check(self.lib.tmpnn_status_error(st), f"tmpnn_ssm_forward[{retry}]")
         return res
+
+    def capture_graph(self, X, S, mask, residue_idx, chain_enc, offsets, max_len: int, out: Optional[dict] = None, **want):
+        """Capture ONE fused forward (its ~20 launches + the status memset) into a hipGraph: -> (graph, out). ``graph.replay()``
+        reruns it on the captured tensors — refill X / S / ... in place for a new protein of the same length. The C-ABI
+        never allocates or synchronises, so the call sequence captures as is; the workspace and the outputs are
+        allocated by a warm-up run before the capture. Removes the per-launch CPU cost that dominates a single small
+        protein (20 launches for ~0.2 ms of GPU work)."""
+        X, mask = self._f32(X), self._f32(mask)
+        S, ridx, cenc, offsets = self._i32(S), self._i32(residue_idx), self._i32(chain_enc), self._i32(offsets)
+        kw = dict(max_len=int(max_len), check_status=False, **want)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            out = self.ssm_forward(X, S, mask, ridx, cenc, offsets, out=out, **kw)        # warm-up: buffers exist afterwards
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.ssm_forward(X, S, mask, ridx, cenc, offsets, out=out, **kw)
+        graph._tmpnn_keepalive = (X, S, mask, ridx, cenc, offsets, out)                    # captured pointers stay valid
+        return graph, out
+
+    def check_last_status(self) -> None:
+        """Raise if the most recent ``ssm_forward(check_status=False)`` flagged a range / max_len problem (syncs)."""
+        st = int(self._status.item())
+        if st:
+            check(self.lib.tmpnn_status_error(st), "tmpnn_ssm_forward")
 
 
 # module-level gathers with the reference's signatures (protein_mpnn_utils.py:763-791)

@@ -21,18 +21,18 @@ def _chains_arg(chains) -> Optional[bytes]:
 def _unpack(lib, handle) -> dict:
     L = lib.tmpnn_pdb_length(handle)
     out = dict(X=np.empty((L, 4, 3), np.float32), S=np.empty(L, np.int32), mask=np.empty(L, np.float32),
-               residue_idx=np.empty(L, np.int32), chain_enc=np.empty(L, np.int32))
+               residue_idx=np.empty(L, np.int32), chain_enc=np.empty(L, np.int32), ca_mask=np.empty(L, np.float32))
     seq = C.create_string_buffer(L + 1)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     _lib.check(lib.tmpnn_pdb_fill(handle, p(out["X"]), p(out["S"]), p(out["mask"]), p(out["residue_idx"]),
-                                  p(out["chain_enc"]), seq), "tmpnn_pdb_fill")
+                                  p(out["chain_enc"]), seq, p(out["ca_mask"])), "tmpnn_pdb_fill")
     out["seq"] = seq.value.decode()
     out["num_of_chains"] = lib.tmpnn_pdb_num_chains(handle)
     return out
 
 
 def parse_pdb(path: str, chains=None) -> dict:
-    """One structure -> dict(X [L,4,3] f32, S, mask, residue_idx, chain_enc, seq, num_of_chains, name)."""
+    """One structure -> dict(X [L,4,3] f32, S, mask, residue_idx, chain_enc, ca_mask, seq, num_of_chains, name)."""
     lib = _lib.load()
     h = C.c_void_p()
     _lib.check(lib.tmpnn_pdb_parse(os.fsencode(path), _chains_arg(chains), C.byref(h)), "tmpnn_pdb_parse")

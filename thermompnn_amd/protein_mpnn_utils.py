@@ -39,6 +39,8 @@ class _EngineOwner(nn.Module):
     _engine = None
     _engine_key = None
     k_neighbors = 48
+    precision = None          # matrix-core path of the engine ("f16x2" | "bf16x3" | "fp32"; None = library default)
+    retry_precision = "bf16x3"   # Engine reruns an f16x2 forward that left the fp16 range at this precision (None: raise)
 
     def _state_for_engine(self):
         return {k: v for k, v in self.state_dict().items()}
@@ -49,9 +51,10 @@ class _EngineOwner(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("thermompnn_amd runs on MI355X only: move the model to a CUDA (ROCm) device "
                                "with .cuda(); there is no CPU execution path")
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (tuple((p.data_ptr(), p._version) for p in params), self.precision, self.retry_precision)
         if self._engine is None or key != self._engine_key:
-            self._engine = Engine(self._state_for_engine(), dev, self.k_neighbors)
+            self._engine = Engine(self._state_for_engine(), dev, self.k_neighbors, precision=self.precision,
+                                  retry_precision=self.retry_precision)
             self._engine_key = key
         return self._engine
 

@@ -6,7 +6,11 @@ one device-to-host copy -> columnar CSV writer. Post-processing options keep the
   --centrality   'neighbors' column = #CA within 10 A (compute_centrality, SSM.py:129-132,144-145)
   --pick_best    keep one row per position carrying best_AA = argmin ddG (retrieve_best_mutants, SSM.py:32-42,153-162)
   --include_cys  otherwise mutations to C are excluded (from the best-pick, or dropped from the listing; :164-166)
-With torch.distributed initialised, proteins are sharded over the ranks (dist.ssm_scan) and rank 0 writes.
+Launched under ``python -m torch.distributed.run --nproc-per-node N -m thermompnn_amd.ssm_scan ...`` the proteins
+are sharded over the N GPUs (dist.ssm_scan: LPT partition, one RCCL all-gather of the tables) and rank 0 writes the
+CSV; a plain ``python -m thermompnn_amd.ssm_scan`` is the same code with a world of one.
+  --mutations FILE   CSV with columns pdb,position,mutation (0-based position into the parsed sequence): only the listed
+                     mutants are written (BASELINE config 4: an explicit list over many proteins)
 """
 from __future__ import annotations
 
@@ -34,35 +38,42 @@ def retrieve_best_mutants(ddg_table: np.ndarray, allow_cys: bool = True) -> List
     return [AA20[i] for i in np.argmin(t, axis=1)]
 
 
-def scan_proteins(engine, proteins: Sequence[dict], centrality: bool = False, chunk_residues: int = 1 << 18):
+def scan_proteins(engine, proteins: Sequence[dict], centrality: bool = False, chunk_residues: int = 1 << 18, group=None):
     """proteins: dicts from native_pdb.parse_pdb. -> (list of [L,21] ddG arrays, list of neighbour-count arrays or None).
-    Proteins are processed in ragged chunks of at most ``chunk_residues`` residues (workspace ~27.5 KB / residue)."""
-    from .dist import pack_proteins
-    tables: List[Optional[np.ndarray]] = [None] * len(proteins)
-    neigh: List[Optional[np.ndarray]] = [None] * len(proteins)
-    order = sorted(range(len(proteins)), key=lambda i: -len(proteins[i]["S"]))
-    i = 0
-    while i < len(order):
-        ids, tot = [], 0
-        while i < len(order) and (not ids or tot + len(proteins[order[i]]["S"]) <= chunk_residues):
-            ids.append(order[i])
-            tot += len(proteins[order[i]]["S"])
-            i += 1
-        b = pack_proteins(proteins, ids, engine.device)
-        ddg = engine.ssm_forward(b["X"], b["S"], b["mask"], b["ridx"], b["cenc"], b["offsets"], max_len=b["max_len"])["ddg"]
-        cen = engine.centrality(b["X"], b["mask"], b["offsets"], 10.0).cpu().numpy() if centrality else None
-        ddg = ddg.cpu().numpy()                                  # one D2H copy per chunk
-        if not np.isfinite(ddg[:, :20]).all():
-            raise RuntimeError("non-finite ddG: the default f16x2 matrix-core path needs |activations| < 65504 — "
-                               "rerun with TMPNN_PRECISION=bf16x3 (full fp32 range)")
-        pos = 0
-        for pid in ids:
-            L = len(proteins[pid]["S"])
-            tables[pid] = ddg[pos:pos + L]
-            if cen is not None:
-                neigh[pid] = cen[pos:pos + L]
-            pos += L
-    return tables, (neigh if centrality else None)
+    Sharded over ``group``'s ranks when torch.distributed is initialised (every rank gets every table back); processed in
+    ragged chunks of at most ``chunk_residues`` residues. Non-finite results never reach the caller: the engine reruns
+    an overflowing f16x2 batch in bf16x3 or raises (Engine.ssm_forward)."""
+    from .dist import ssm_scan
+    res = ssm_scan(engine, proteins, group=group, centrality=centrality, chunk_residues=chunk_residues)
+    tables, cen = res if centrality else (res, None)
+    flat = torch.cat([t.reshape(-1) for t in tables]).cpu().numpy() if tables else np.zeros(0, np.float32)   # one D2H copy
+    out, pos = [], 0
+    for t in tables:
+        n = t.shape[0] * 21
+        out.append(flat[pos:pos + n].reshape(-1, 21))
+        pos += n
+    neigh = [c.cpu().numpy() for c in cen] if cen is not None else None
+    return out, neigh
+
+
+def read_mutation_list(path: str, proteins: Sequence[dict]):
+    """CSV with columns pdb,position,mutation[,wildtype] -> int64 [M,3] triples (protein index, position, aa index).
+    ``pdb`` matches the parsed structure's name; a stated wildtype must agree with the structure's residue (the
+    reference asserts this too, custom_inference.py:86-87)."""
+    by_name = {p["name"]: i for i, p in enumerate(proteins)}
+    out = []
+    with open(path, newline="") as fh:
+        for r in csv.DictReader(fh):
+            if r["pdb"] not in by_name:
+                raise KeyError(f"{path}: unknown pdb {r['pdb']!r}")
+            i, pos, mut = by_name[r["pdb"]], int(r["position"]), r["mutation"].strip()
+            seq = proteins[i]["seq"]
+            assert 0 <= pos < len(seq), f"{r['pdb']}: position {pos} outside the {len(seq)}-residue sequence"
+            assert mut in AA20, f"{r['pdb']}: unknown amino acid {mut!r}"
+            wt = (r.get("wildtype") or "").strip()
+            assert not wt or wt == seq[pos], f"{r['pdb']}: wildtype {wt}{pos} does not match the structure ({seq[pos]})"
+            out.append((i, pos, AA20.index(mut)))
+    return np.asarray(out, dtype=np.int64).reshape(-1, 3)
 
 
 def rows_for_protein(p: dict, table: np.ndarray, neighbors, model_name: str, dataset: str, pick_best: bool,
@@ -107,20 +118,38 @@ def main(argv=None):
     ap.add_argument("--pick_best", action="store_true", default=False, help="Keep only the BEST mutation at each position")
     ap.add_argument("--include_cys", action="store_true", default=False, help="Include cysteine as potential mutation option.")
     ap.add_argument("--centrality", action="store_true", default=False, help="Calculate centrality value for each residue (# neighbors).")
+    ap.add_argument("--mutations", default="", help="CSV (pdb,position,mutation): write only these mutants")
+    ap.add_argument("--precision", default=None, choices=["f16x2", "bf16x3", "fp32"])
     args = ap.parse_args(argv)
 
+    from . import dist as tdist
     from .custom_inference import load_model
-    model = load_model(args.model_path, args.thermompnn_dir, args.synthetic_weights)
+    rank, world, device = tdist.init_from_env()
+    model = load_model(args.model_path, args.thermompnn_dir, args.synthetic_weights, device=device, precision=args.precision)
     engine = model.engine()
     proteins = native_pdb.parse_pdbs(args.pdbs, [args.chain] * len(args.pdbs))
     with torch.cuda.device(engine.device):
         tables, neigh = scan_proteins(engine, proteins, centrality=args.centrality)
-    rows = []
-    for i, p in enumerate(proteins):
-        rows += rows_for_protein(p, tables[i], neigh[i] if neigh else None, "ThermoMPNN", args.dataset_name,
-                                 args.pick_best, args.include_cys)
-    write_csv(rows, args.out)
-    print(f"Saved {len(rows)} rows for {len(proteins)} proteins to {args.out}")
+    if rank == 0:
+        rows = []
+        if args.mutations:
+            tri = read_mutation_list(args.mutations, proteins)
+            for i, pos, a in tri:
+                p = proteins[i]
+                rows.append({"WT Seq": p["seq"], "Model": "ThermoMPNN", "Dataset": args.dataset_name,
+                             "ddG_pred": float(tables[i][pos, a]), "position": int(pos), "wildtype": p["seq"][pos],
+                             "mutation": AA20[a], "neighbors": int(neigh[i][pos]) if neigh else "", "best_AA": "",
+                             "pdb": p["name"].strip(".pdb")})
+        else:
+            for i, p in enumerate(proteins):
+                rows += rows_for_protein(p, tables[i], neigh[i] if neigh else None, "ThermoMPNN", args.dataset_name,
+                                         args.pick_best, args.include_cys)
+        write_csv(rows, args.out)
+        print(f"Saved {len(rows)} rows for {len(proteins)} proteins to {args.out} ({world} rank(s))")
+    if world > 1:
+        import torch.distributed as td
+        td.barrier()
+        td.destroy_process_group()
     return args.out
 
 

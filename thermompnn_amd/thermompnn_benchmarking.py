@@ -1,6 +1,7 @@
 """Counterparts of the hot-path-adjacent symbols of /root/reference/analysis/thermompnn_benchmarking.py
-(SURVEY.md §8f ranks 2-3): compute_centrality (:20-35), ProteinMPNNBaseline (:38-65), get_trained_model (:78-84).
-Metrics / dataset drivers of that file stay out of scope."""
+(SURVEY.md §8f ranks 2-4): compute_centrality (:20-35), ProteinMPNNBaseline (:38-65), get_trained_model (:78-84), and the
+per-dataset evaluation loops run_prediction_default / run_prediction_keep_preds (:87-187) over the CSV datasets of
+thermompnn_amd.datasets, scored with thermompnn_amd.metrics (torchmetrics / pandas / tqdm are not needed)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -69,3 +70,65 @@ def get_trained_model(model_name, config, checkpt_dir="models/", override_custom
     model = TransferModel(config)
     model.load_state_dict(load_thermompnn_checkpoint(path))
     return model
+
+
+def run_prediction_default(name, model, dataset_name, dataset, results, keep_preds: bool = False):
+    """Reference loop (:87-119): ``model(pdb, mutations)`` per protein, metrics over every mutation with a measured ddG.
+    Appends {"Model", "Dataset", "ddG r2" ... "ddG pearson"} to ``results``; with ``keep_preds`` also returns the raw rows
+    (the run_prediction_keep_preds variant, :122-187, without pandas)."""
+    from .metrics import get_metrics
+    pred_all, true_all, rows = [], [], []
+    for pdb, mutations in dataset:
+        if not mutations:
+            continue
+        with torch.no_grad():
+            pred, _ = model(pdb, mutations)
+        keep = [(m, o) for m, o in zip(mutations, pred) if o is not None and m.ddG is not None]
+        if not keep:
+            continue
+        vals = torch.cat([o["ddG"].reshape(1) for _, o in keep]).cpu().tolist()        # one D2H copy per protein
+        for (m, _), v in zip(keep, vals):
+            pred_all.append(v)
+            true_all.append(float(m.ddG))
+            if keep_preds:
+                rows.append({"Model": name, "Dataset": dataset_name, "ddG_true": float(m.ddG), "ddG_pred": v,
+                             "position": m.position, "wildtype": m.wildtype, "mutation": m.mutation,
+                             "pdb": (m.pdb or "").strip(".pdb")})
+    met = get_metrics(pred_all, true_all)
+    column = {"Model": name, "Dataset": dataset_name}
+    for k in ("r2", "mse", "rmse", "spearman", "pearson"):
+        column[f"ddG {k}"] = met[k]
+    column["n"] = met["n"]
+    results.append(column)
+    return (results, rows) if keep_preds else results
+
+
+def run_prediction_batched(name, engine, dataset_name, dataset, results, group=None):
+    """The same evaluation on the batched path: every protein of the dataset goes through ONE ragged dist.ssm_scan (sharded
+    over ``group``'s GPUs when torch.distributed is initialised) and the listed mutations are picked out of the [L, 21]
+    tables with dist.select_mutations. Equivalent to run_prediction_default for mutations whose stated wild type matches
+    the structure (the datasets guarantee that) — and one forward per dataset instead of one per protein."""
+    from . import dist as tdist
+    from .metrics import get_metrics
+    from .pdb_io import tied_featurize
+    prots, triples, truth = [], [], []
+    for pdb, mutations in dataset:
+        muts = [m for m in mutations if m is not None and m.ddG is not None and m.mutation in ALPHABET[:20]]
+        if not muts:
+            continue
+        f = tied_featurize([pdb[0]], "cpu", None, None, None, None, None, None, ca_only=False)
+        pid = len(prots)
+        prots.append(dict(X=f[0][0].numpy(), S=f[1][0].numpy().astype(np.int32), mask=f[2][0].numpy(),
+                          residue_idx=f[12][0].numpy().astype(np.int32), chain_enc=f[5][0].numpy().astype(np.int32)))
+        for m in muts:
+            assert pdb[0]["seq"][m.position] == m.wildtype, "batched evaluation needs the structure's own wild type"
+            triples.append((pid, m.position, ALPHABET.index(m.mutation)))
+            truth.append(float(m.ddG))
+    tables = tdist.ssm_scan(engine, prots, group=group)
+    pred = tdist.select_mutations(tables, np.asarray(triples, dtype=np.int64)).cpu().numpy()
+    met = get_metrics(pred, truth)
+    column = {"Model": name, "Dataset": dataset_name, "n": met["n"]}
+    for k in ("r2", "mse", "rmse", "spearman", "pearson"):
+        column[f"ddG {k}"] = met[k]
+    results.append(column)
+    return results

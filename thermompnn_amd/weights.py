@@ -132,7 +132,7 @@ def save_vanilla_checkpoint(path, mpnn_sd, num_edges: int = 48) -> None:
 
 def load_vanilla_checkpoint(path):
     """-> (num_edges, state_dict). Mirrors transfer_model.py:25-29."""
-    ckpt = torch.load(path, map_location="cpu")
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
     return int(ckpt["num_edges"]), ckpt["model_state_dict"]
 
 
@@ -140,15 +140,34 @@ def save_lightning_checkpoint(path, transfer_sd) -> None:
     torch.save({"state_dict": OrderedDict(("model." + k, v) for k, v in transfer_sd.items())}, path)
 
 
-def load_thermompnn_checkpoint(path):
-    """Read a TransferModelPL checkpoint without importing Lightning: strips the ``model.`` prefix
-    (train_thermompnn.py:28-40 registers the TransferModel as ``self.model``)."""
+def load_thermompnn_checkpoint(path, allow_pickle: bool = None):
+    """Read a TransferModelPL checkpoint without importing Lightning (train_thermompnn.py:28-40 registers the
+    TransferModel as ``self.model``): keeps ONLY the ``model.*`` entries of ``state_dict`` (Lightning-level buffers,
+    metric states, optimizer state and ``hyper_parameters`` are dropped) and strips the prefix.
+
+    The file is read with ``torch.load(weights_only=True)`` (tensors and plain containers only). Checkpoints whose
+    ``hyper_parameters`` hold arbitrary Python objects (an OmegaConf config) need the pickle loader, which executes code
+    from the file: that is an explicit opt-in — ``allow_pickle=True`` or TMPNN_ALLOW_PICKLE=1 — for files you trust."""
+    import os
+    import pickle
+    if allow_pickle is None:
+        allow_pickle = os.environ.get("TMPNN_ALLOW_PICKLE") == "1"
     try:
-        ckpt = torch.load(path, map_location="cpu")
-    except Exception:  # Lightning checkpoints carry non-tensor hyper-parameter objects
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        if not allow_pickle:
+            raise RuntimeError(f"{path}: not loadable with weights_only=True ({str(e).splitlines()[0][:200]}). If you trust "
+                               "this file, pass allow_pickle=True (or set TMPNN_ALLOW_PICKLE=1) to use the pickle "
+                               "loader, which can execute code embedded in the checkpoint.") from e
         ckpt = torch.load(path, map_location="cpu", weights_only=False)
-    sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
     out = OrderedDict()
-    for k, v in sd.items():
-        out[k[len("model."):] if k.startswith("model.") else k] = v
+    if isinstance(ckpt, dict) and "state_dict" in ckpt:
+        for k, v in ckpt["state_dict"].items():
+            if k.startswith("model."):
+                out[k[len("model."):]] = v
+        if not out:
+            raise KeyError(f"{path}: 'state_dict' has no 'model.*' entries (not a TransferModelPL checkpoint?)")
+    else:                                       # a bare TransferModel state dict
+        for k, v in ckpt.items():
+            out[k[len("model."):] if k.startswith("model.") else k] = v
     return out
