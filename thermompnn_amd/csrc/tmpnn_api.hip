@@ -110,13 +110,22 @@ static int default_mode() {                  // TMPNN_PRECISION, read once; an u
     return v;
 }
 static thread_local int g_mode = -1;         // mode of the API call in progress (TmModeScope), -1 = none
+static thread_local const tmpnn_weights *g_cur_w = nullptr;
+const tmpnn_weights *tm_cur_weights() { return g_cur_w; }
+const char *tm_find_wimg(const float *base) {
+    const tmpnn_weights *w = g_cur_w;
+    if (!w || !base) return nullptr;
+    for (int i = 0; i < w->n_wimg; ++i)
+        if (w->wimg[i].base == base) return w->wimg[i].img;
+    return nullptr;
+}
 int tm_matmul_mode() {
     if (g_mode >= 0) return g_mode;
     const int d = default_mode();
     return d < 0 ? (int)TM_MM_F16X2 : d;
 }
-TmModeScope::TmModeScope(int mode) : saved(g_mode) { g_mode = mode; }
-TmModeScope::~TmModeScope() { g_mode = saved; }
+TmModeScope::TmModeScope(const tmpnn_weights *w) : saved(g_mode), saved_w(g_cur_w) { g_mode = w->mode; g_cur_w = w; }
+TmModeScope::~TmModeScope() { g_mode = saved; g_cur_w = saved_w; }
 extern "C" const char *tmpnn_matmul_mode(void) { return mode_name(tm_matmul_mode()); }
 extern "C" const char *tmpnn_weights_precision(const tmpnn_weights_t *w) { return w ? mode_name(w->mode) : nullptr; }
 
@@ -192,7 +201,8 @@ extern "C" int64_t tmpnn_tensor_numel(int i) {
 static const size_t POS_TABLE_FLOATS = 66 * TMPNN_HID, SEQ_TABLE_FLOATS = TMPNN_VOCAB * TMPNN_HID,
                     CONV_CENTER_FLOATS = 384 * 384, W13L_BYTES = 32768;
 extern "C" size_t tmpnn_weights_packed_bytes(void) {
-    return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float) + 3 * W13L_BYTES;
+    return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float) + 3 * W13L_BYTES +
+           (size_t)TM_N_WIMG * TM_WIMG_BYTES;
 }
 
 extern "C" int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *tensors, int n_tensors, void *packed,
@@ -282,6 +292,25 @@ extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const 
     for (int l = 0; l < 3; ++l) w->enc[l].W13l = (const char *)p + (size_t)l * W13L_BYTES;
     int rc = launch_prep_tables(w, (hipStream_t)stream);
     for (int l = 0; l < 3 && rc == TMPNN_OK; ++l) rc = launch_wt_prep(w->enc[l].W13, (char *)w->enc[l].W13l, (hipStream_t)stream);
+    {   // fragment images of every 128 x 128 block the node kernels multiply by (see WImg)
+        char *img = (char *)p + 3 * W13L_BYTES;
+        auto add = [&](const float *base, int ld) {
+            if (rc != TMPNN_OK || w->n_wimg >= TM_N_WIMG) return;
+            w->wimg[w->n_wimg++] = WImg{base, img};
+            rc = launch_prep_wimg(base, ld, img, (hipStream_t)stream);
+            img += TM_WIMG_BYTES;
+        };
+        for (int l = 0; l < 3; ++l) {
+            const EncW &e = w->enc[l];
+            add(e.W3, 128);
+            for (int c = 0; c < 4; ++c) { add(e.Win + (size_t)128 * c * 128, 128); add(e.Wout + 128 * c, 512); }
+            add(e.W1, 384); add(e.W1 + 256, 384); add(e.W11, 384); add(e.W11 + 256, 384);
+            const DecW &d = w->dec[l];
+            add(d.W3, 128);
+            for (int c = 0; c < 4; ++c) { add(d.Win + (size_t)128 * c * 128, 128); add(d.Wout + 128 * c, 512); }
+            add(d.W1, 512); add(d.W1 + 384, 512);
+        }
+    }
     if (rc != TMPNN_OK) { delete w; return rc; }
     *out = w;
     return TMPNN_OK;
@@ -401,7 +430,7 @@ extern "C" int tmpnn_edge_featurize(const tmpnn_weights_t *w, const float *X, co
     REQUIRE(w && X && residue_idx && chain_enc && E_idx && D_nb && h_E, "edge_featurize: null pointer");
     REQUIRE(T >= 0 && T <= T_MAX, "edge_featurize: bad T");
     if (T == 0) return TMPNN_OK;
-    const TmModeScope scope(w->mode);
+    const TmModeScope scope(w);
     return launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, h_E, E_opt, (hipStream_t)stream);
 }
 
@@ -436,7 +465,7 @@ extern "C" int tmpnn_enc_layer(const tmpnn_weights_t *w, int layer, float *h_V, 
     REQUIRE(layer >= 0 && layer < 3, "enc_layer: layer %d outside [0,3)", layer);
     REQUIRE(T >= 0 && T <= T_MAX, "enc_layer: bad T");
     if (T == 0) return TMPNN_OK;
-    const TmModeScope scope(w->mode);
+    const TmModeScope scope(w);
     LayerWs ws;
     TRY(carve_layer_ws(workspace, workspace_bytes, T, &ws));
     return run_enc_layer(w, layer, h_V, h_E, E_idx, mask, T, ws, false, nullptr, (hipStream_t)stream);
@@ -446,7 +475,7 @@ extern "C" int tmpnn_enc_layer(const tmpnn_weights_t *w, int layer, float *h_V, 
 extern "C" int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const float *P, float *h_E, const int32_t *E_idx,
                                      int64_t T, int ablation, tmpnn_stream_t stream) {
     REQUIRE(w && P && h_E && E_idx && layer >= 0 && layer < 3 && T > 0 && T <= T_MAX, "ablate_enc_edge: bad argument");
-    const TmModeScope scope(w->mode);
+    const TmModeScope scope(w);
     return launch_enc_edge(w->enc[layer], P, h_E, E_idx, T, (hipStream_t)stream, ablation);
 }
 
@@ -469,7 +498,7 @@ extern "C" int tmpnn_dec_layer(const tmpnn_weights_t *w, int layer, const float 
     REQUIRE(layer >= 0 && layer < 3, "dec_layer: layer %d outside [0,3)", layer);
     REQUIRE(T >= 0 && T <= T_MAX, "dec_layer: bad T");
     if (T == 0) return TMPNN_OK;
-    const TmModeScope scope(w->mode);
+    const TmModeScope scope(w);
     LayerWs ws;
     TRY(carve_layer_ws(workspace, workspace_bytes, T, &ws));
     return run_dec_layer(w, layer, h_V_in, h_V_out, h_E, E_idx, S, mask, T, ws, false, nullptr, (hipStream_t)stream);
@@ -493,7 +522,7 @@ extern "C" int tmpnn_ddg_head(const tmpnn_weights_t *w, const float *hV_last, co
     REQUIRE(w && hV_last && hV_prev && S && ddg && T >= 0 && T <= T_MAX, "ddg_head: bad argument");
     REQUIRE(w->n_tensors == TMPNN_N_TENSORS, "ddg_head: weight handle was created without the TransferModel head tensors");
     if (T == 0) return TMPNN_OK;
-    const TmModeScope scope(w->mode);
+    const TmModeScope scope(w);
     return launch_head(w, hV_last, hV_prev, S, T, ddg, z_opt, status_opt, (hipStream_t)stream);
 }
 
@@ -512,7 +541,7 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     REQUIRE(max_len >= 1, "ssm_forward: max_len must be >= 1 (the longest protein of the batch)");
     if (max_len > 8192) return tm_set_error(TMPNN_E_UNSUPPORTED, "ssm_forward: max_len %d > 8192", max_len);
     hipStream_t st = (hipStream_t)stream;
-    const TmModeScope scope(w->mode);
+    const TmModeScope scope(w);
     if (status_opt && hipMemsetAsync(status_opt, 0, sizeof(int32_t), st) != hipSuccess)
         return tm_set_error(TMPNN_E_LAUNCH, "ssm_forward: status memset failed");
 

@@ -16,9 +16,18 @@ struct DecW {
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     const float *Win, *bin, *Wout, *bout;
 };
+// Pre-built f16x2 MFMA A-fragment image of one 128 x 128 weight block for the 8-wavefront node kernels: 64 KB,
+// [wavefront 8][k-step 4][plane 2][lane 64] x 16 B — a wavefront's fragment is four coalesced 1 KB loads per plane
+// instead of 16-row gathers of fp32 that are split on the fly (tmpnn_split.hip: node_update8_split_kernel).
+#define TM_WIMG_BYTES 65536
+#define TM_N_WIMG 72           // enc: W3 + 4 W_in + 4 W_out + W1a W1c W11a W11c (13) x 3; dec: W3 + 4 + 4 + W1a W1d (11) x 3
+struct WImg { const float *base; const char *img; };      // base = address of the block's element [0][0] in the raw tensor
+
 struct tmpnn_weights {
     int n_tensors;
     int mode;              // TM_MM_*: matrix-core path of this handle's per-edge GEMMs
+    WImg wimg[TM_N_WIMG];  // derived fragment images (in the caller's packed buffer), looked up by block base address
+    int n_wimg;
     const float *t[TMPNN_N_TENSORS];
     // features
     const float *pos_w, *pos_b, *edge_w, *norm_edges_w, *norm_edges_b, *We_w, *We_b, *Ws_w;
@@ -71,6 +80,7 @@ struct NodeArgs {
     float *h_out;
     int T;
     ProjSpec proj[2];       // proj[k].P == nullptr -> not requested
+    const char *img[13];    // fragment images of the 13 GEMM units (W3, W_in/W_out chunk pairs, projections) or all null
 };
 int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st);
 int launch_node_proj(const float *h, const NodeProj &np, int64_t T, hipStream_t st);
@@ -105,11 +115,15 @@ int tm_num_cus();
 // TMPNN_PRECISION = f16x2 (default) | bf16x3 | fp32 only picks the default of handles created without one.
 enum { TM_MM_FP32 = 0, TM_MM_BF16X3 = 1, TM_MM_F16X2 = 2 };
 int tm_matmul_mode();                 // mode of the API call in progress on this thread (set from the handle)
+const tmpnn_weights *tm_cur_weights();   // handle of the API call in progress (nullptr outside one)
 struct TmModeScope {                  // entry points that take a handle open one of these
     int saved;
-    explicit TmModeScope(int mode);
+    const tmpnn_weights *saved_w;
+    explicit TmModeScope(const tmpnn_weights *w);
     ~TmModeScope();
 };
+int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st);       // tmpnn_split.hip
+const char *tm_find_wimg(const float *base);                                   // nullptr if no image (or no handle in scope)
 // Non-finite tests under -fno-honor-nans. The kernels are built with relaxed NaN semantics, so hipcc may fold a NaN test
 // on the RESULT of floating-point arithmetic (measured: both the sum test and the exponent-bit test on a computed value
 // were compiled away; only the inf half survives). Tests are therefore made on raw bits LOADED FROM MEMORY, before any

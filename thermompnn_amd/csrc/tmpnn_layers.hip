@@ -1017,6 +1017,18 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
     for (int k = 0; k < 2; ++k)
         a.proj[k] = ps[k] ? ProjSpec{ps[k]->Wa, ps[k]->lda, ps[k]->ba, ps[k]->Wc, ps[k]->ldc, ps[k]->P, ps[k]->add_tab, ps[k]->add_idx}
                           : ProjSpec{nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    {   // pre-built fragment images (all 13 units or none)
+        const float *base[13] = {W3};
+        for (int c = 0; c < 4; ++c) { base[1 + 2 * c] = Win + (size_t)128 * c * 128; base[2 + 2 * c] = Wout + 128 * c; }
+        for (int k = 0; k < 2; ++k) { base[9 + 2 * k] = ps[k] ? ps[k]->Wa : nullptr; base[10 + 2 * k] = ps[k] ? ps[k]->Wc : nullptr; }
+        bool all = true;
+        for (int u = 0; u < 13; ++u) {
+            a.img[u] = base[u] ? tm_find_wimg(base[u]) : nullptr;
+            if (base[u] && !a.img[u]) all = false;
+        }
+        static const bool img_off = [] { const char *e = getenv("TMPNN_NODE_IMG"); return e != nullptr && e[0] == '0'; }();
+        if (!all || img_off) for (int u = 0; u < 13; ++u) a.img[u] = nullptr;
+    }
     tm_prof_begin("node_update", st);
     // Tile height (16 / 32 / 48 residues) chosen for load balance: the grid offers 2 workgroup slots per CU, every
     // tile streams the same ~0.8 MB of weights from L2 (worth about 16 rows of MFMA time), so minimise

@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_update_split_kernel(NodeAr
 // is requested before the MFMAs of GEMM u and split into f16 planes after them, so no GEMM waits on an L2 round trip
 // (the 4-wavefront form above does, 13 times per tile); the taller tile halves the weight traffic per residue.
 // ------------------------------------------------------------------------------------------------
-template <typename SP, int NRB>
+template <typename SP, int NRB, bool IMG>
 __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) {
     constexpr int ROWS = 16 * NRB, PLT = SP::NP * ROWS * 256;
     static_assert(PLT >= ROWS * TM_H * 4, "the fp32 LayerNorm-2 input is aliased on the plane tile pA");
@@ -1044,8 +1044,21 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
         const ProjSpec &ps = a.proj[(u - 9) >> 1];
         return ((u - 9) & 1) ? ps.Wc + r * ps.ldc + 8 * q : ps.Wa + r * ps.lda + 8 * q;
     };
+    // With pre-built fragment images (NodeArgs::img, built by tmpnn_weights_create) a unit's fragment is 8 coalesced 1 KB
+    // loads of ready-made f16 planes; without them (standalone callers) it is gathered from 16 fp32 rows per load and split
+    // on the fly. Measured (MI355X): 22.9 vs 30.3 us per launch on a single L=256 protein — the strided gathers ran at a
+    // third of the L2 -> CU fill rate and every one of the 9-13 dependent GEMM units of a tile waited for them.
     f4 raw[8];
     auto issue = [&](int u) {
+        if constexpr (IMG) {
+            const char *p = a.img[u] + (size_t)wv * 8192 + lane * 16;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                raw[2 * c] = *reinterpret_cast<const f4 *>(p + 2048 * c);
+                raw[2 * c + 1] = *reinterpret_cast<const f4 *>(p + 2048 * c + 1024);
+            }
+            return;
+        }
         const float *p = src(u);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1055,6 +1068,15 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
     };
     WFragS<SP> wf[1][4];
     auto split_raw = [&]() {
+        if constexpr (IMG) {
+            static_assert(SP::NP == 2, "the fragment images hold the two f16x2 planes");
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                wf[0][c].p[0] = __builtin_bit_cast(u4, raw[2 * c]);
+                wf[0][c].p[1] = __builtin_bit_cast(u4, raw[2 * c + 1]);
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             unsigned w4[4][SP::NP];
@@ -1187,6 +1209,27 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
     }
 }
 
+// fragment image of one 128 x 128 block (see WImg in tmpnn_internal.h): [wv 8][c 4][plane 2][lane 64] x 16 B
+__global__ void prep_wimg_kernel(const float *__restrict__ W, int ld, char *__restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (wv, c, lane)
+    if (idx >= 8 * 4 * 64) return;
+    const int lane = idx & 63, c = (idx >> 6) & 3, wv = idx >> 8, m = lane & 15, q = lane >> 4;
+    const float *src = W + (size_t)(16 * wv + m) * ld + 32 * c + 8 * q;
+    const f4 v0 = ld4(src), v1 = ld4(src + 4);
+    unsigned w4[4][2];
+    SplitH2::split2(f2{v0.x, v0.y}, w4[0]);
+    SplitH2::split2(f2{v0.z, v0.w}, w4[1]);
+    SplitH2::split2(f2{v1.x, v1.y}, w4[2]);
+    SplitH2::split2(f2{v1.z, v1.w}, w4[3]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        *reinterpret_cast<u4 *>(dst + (size_t)wv * 8192 + c * 2048 + p * 1024 + lane * 16) = u4{w4[0][p], w4[1][p], w4[2][p], w4[3][p]};
+}
+int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st) {
+    prep_wimg_kernel<<<8, 256, 0, st>>>(W, ld, dst);
+    return tm_check_launch("prep_wimg");
+}
+
 int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
     // tile height for load balance, as in launch_node_update; the weight stream is worth more rows of (cheaper) matrix time
     static const int wcost = [] { const char *e = getenv("TMPNN_NODE_WCOST"); return e ? atoi(e) : 48; }();
@@ -1203,12 +1246,16 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
         }
         const int64_t tiles = (T + best_rows - 1) / best_rows;
         const int grid = (int)(tiles < slots ? tiles : slots);
+#define TM_NODE8(NRB)                                                                    \
+    if (a.img[0]) node_update8_split_kernel<SplitH2, NRB, true><<<grid, 512, 0, st>>>(a); \
+    else node_update8_split_kernel<SplitH2, NRB, false><<<grid, 512, 0, st>>>(a)
         switch (best_rows) {
-            case 16: node_update8_split_kernel<SplitH2, 1><<<grid, 512, 0, st>>>(a); break;
-            case 32: node_update8_split_kernel<SplitH2, 2><<<grid, 512, 0, st>>>(a); break;
-            case 48: node_update8_split_kernel<SplitH2, 3><<<grid, 512, 0, st>>>(a); break;
-            default: node_update8_split_kernel<SplitH2, 4><<<grid, 512, 0, st>>>(a); break;
+            case 16: TM_NODE8(1); break;
+            case 32: TM_NODE8(2); break;
+            case 48: TM_NODE8(3); break;
+            default: TM_NODE8(4); break;
         }
+#undef TM_NODE8
         return tm_check_launch("node_update8_split");
     }
     const int64_t slots = (int64_t)2 * tm_num_cus();

@@ -10,7 +10,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o $c -- python $R/tools/pmc_workload.py > $OUT/$c.log 2>&1
 done
 python - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, sys
+sys.path.insert(0, "$R")
+from bench import kernel_source_stamp
 LOGICAL = [("enc_edge", "enc_edge"), ("msg4_rp_kernel<SplitH2, false", "enc_msg"), ("msg8_rp_kernel<SplitH2, false", "enc_msg"),
            ("msg4_rp_kernel<SplitH2, true", "dec_msg"), ("msg8_rp_kernel<SplitH2, true", "dec_msg"), ("featurize", "featurize"),
            ("gather_rows_kernel", "gather_rows"), ("copyBuffer", "device_copy_calibration"), ("node_update", "node_update"),
@@ -44,7 +46,7 @@ for (c, k), (m, n) in mean.items():
 for name, d in kern.items():
     d["traffic_bytes"] = d.get("fetch_bytes", 0) + d.get("write_bytes", 0)
     if name in ALG: d["algorithmic_bytes"] = ALG[name]; d["ratio"] = d["traffic_bytes"] / ALG[name]
-json.dump({"units": "bytes per launch at T=16384 residues (64 x L=256); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section "
+json.dump({"kernel_source_stamp": kernel_source_stamp(), "units": "bytes per launch at T=16384 residues (64 x L=256); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section "
            "(gfx950 reports 1/2 of wide coalesced reads; confirmed on the 402.7 MB device copy), WRITE_SIZE exact (KB = 1024 B)",
            "kernels": kern}, open("$OUT/pmc_traffic.json", "w"), indent=1)
 for n, d in kern.items(): print(n, d.get("traffic_bytes"), d.get("algorithmic_bytes"), d.get("ratio"))
