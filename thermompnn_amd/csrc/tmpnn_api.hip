@@ -305,10 +305,12 @@ extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const 
             add(e.W3, 128);
             for (int c = 0; c < 4; ++c) { add(e.Win + (size_t)128 * c * 128, 128); add(e.Wout + 128 * c, 512); }
             add(e.W1, 384); add(e.W1 + 256, 384); add(e.W11, 384); add(e.W11 + 256, 384);
+            add(e.W1 + 128, 384); add(e.W2, 128); add(e.W11 + 128, 384); add(e.W12, 128); add(e.W13, 128);   // per-edge kernels
             const DecW &d = w->dec[l];
             add(d.W3, 128);
             for (int c = 0; c < 4; ++c) { add(d.Win + (size_t)128 * c * 128, 128); add(d.Wout + 128 * c, 512); }
             add(d.W1, 512); add(d.W1 + 384, 512);
+            add(d.W1 + 128, 512); add(d.W2, 128);
         }
     }
     if (rc != TMPNN_OK) { delete w; return rc; }
@@ -374,11 +376,12 @@ static NodeProj dec_msg_proj(const tmpnn_weights *w, int l, float *P, const int3
 
 // have_P: ws.P already holds this layer's message projection (written by the previous node_update)
 static int run_enc_layer(const tmpnn_weights *w, int l, float *hV, float *hE, const int32_t *E_idx, const float *mask,
-                         int64_t T, const LayerWs &ws, bool have_P, const NodeProj *next, hipStream_t st) {
+                         int64_t T, const LayerWs &ws, bool have_P, const NodeProj *next, hipStream_t st, bool hV_is_zero = false) {
     const EncW &e = w->enc[l];
     if (!have_P) {
         const NodeProj mp = enc_msg_proj(w, l, ws.P);
-        TRY(launch_node_proj(hV, mp, T, st));
+        if (hV_is_zero) TRY(launch_node_proj_zero(mp, T, st));
+        else TRY(launch_node_proj(hV, mp, T, st));
     }
     // message + node update (EncLayer :819-832); the update also projects the NEW state for the edge update
     TRY(launch_msg(false, e.W1 + 128, 384, e.W2, e.b2, ws.P, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
@@ -566,7 +569,7 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     // very first projection (of the all-zero state) is a separate launch: 20 launches per forward instead of 28
     for (int l = 0; l < 3; ++l) {
         const NodeProj next = l < 2 ? enc_msg_proj(w, l + 1, ws.P) : dec_msg_proj(w, 0, ws.P, S);
-        TRY(run_enc_layer(w, l, hV[0], hE, E_idx, mask, T, ws, l > 0, &next, st));
+        TRY(run_enc_layer(w, l, hV[0], hE, E_idx, mask, T, ws, l > 0, &next, st, l == 0));
     }
     for (int l = 0; l < 3; ++l) {
         const NodeProj next = dec_msg_proj(w, l < 2 ? l + 1 : 2, ws.P, S);

@@ -20,7 +20,7 @@ struct DecW {
 // [wavefront 8][k-step 4][plane 2][lane 64] x 16 B — a wavefront's fragment is four coalesced 1 KB loads per plane
 // instead of 16-row gathers of fp32 that are split on the fly (tmpnn_split.hip: node_update8_split_kernel).
 #define TM_WIMG_BYTES 65536
-#define TM_N_WIMG 72           // enc: W3 + 4 W_in + 4 W_out + W1a W1c W11a W11c (13) x 3; dec: W3 + 4 + 4 + W1a W1d (11) x 3
+#define TM_N_WIMG 93           // enc: W3 + 4 W_in + 4 W_out + W1a W1c W11a W11c + W1e W2 W11e W12 W13 (18) x 3; dec: W3 + 4 + 4 + W1a W1d + W1e W2 (13) x 3
 struct WImg { const float *base; const char *img; };      // base = address of the block's element [0][0] in the raw tensor
 
 struct tmpnn_weights {
@@ -84,6 +84,7 @@ struct NodeArgs {
 };
 int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st);
 int launch_node_proj(const float *h, const NodeProj &np, int64_t T, hipStream_t st);
+int launch_node_proj_zero(const NodeProj &np, int64_t T, hipStream_t st);       // the same for h == 0 (a fill)
 int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
                        const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,

@@ -76,11 +76,29 @@ int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_
 // buffer by LDS-DMA under GEMM 1 and is split into the e planes during the LayerNorm/store phase. Residual: bf16x3
 // re-joins the e planes (exact); f16x2 keeps the fp32 tile (two staging buffers, alternating).
 // ------------------------------------------------------------------------------------------------
+// Weight fragment of wavefront wv from a pre-built image (WImg, tmpnn_internal.h): 8 coalesced 16-byte loads instead of the
+// 16-row fp32 gathers + on-the-fly split of load_wfrag_split. img == nullptr -> the gather path.
+template <typename SP>
+__device__ __forceinline__ void load_wfrag_auto(const char *img, const float *__restrict__ W, int ld, int wv, int lane,
+                                                WFragS<SP> (&wf)[4]) {
+    if (img != nullptr && SP::NP == 2) {
+        const char *p = img + (size_t)wv * 8192 + lane * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            wf[c].p[0] = *reinterpret_cast<const u4 *>(p + 2048 * c);
+            wf[c].p[1] = *reinterpret_cast<const u4 *>(p + 2048 * c + 1024);
+        }
+    } else {
+        load_wfrag_split<SP, 4>(W, ld, 16 * wv, 0, TM_H, wf, lane);
+    }
+}
+
 struct EdgeArgsB {
     const float *W11e, *W12, *b12, *W13, *b13, *g3, *be3, *P;
     float *hE;
     const int32_t *E_idx;
     int T;
+    const char *img11, *img12, *img13;      // fragment images of the three weights (f16x2 only) or null
 };
 
 template <typename SP>
@@ -244,9 +262,9 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
     WFragS<SP> w11[1][4], w12[1][4], w13[1][4];
-    load_wfrag_split<SP, 4>(a.W11e, 384, 16 * wv, 0, TM_H, w11[0], lane);
-    load_wfrag_split<SP, 4>(a.W12, TM_H, 16 * wv, 0, TM_H, w12[0], lane);
-    load_wfrag_split<SP, 4>(a.W13, TM_H, 16 * wv, 0, TM_H, w13[0], lane);
+    load_wfrag_auto<SP>(a.img11, a.W11e, 384, wv, lane, w11[0]);
+    load_wfrag_auto<SP>(a.img12, a.W12, TM_H, wv, lane, w12[0]);
+    load_wfrag_auto<SP>(a.img13, a.W13, TM_H, wv, lane, w13[0]);
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
     const int c32 = lane & 31;
     const f4 b12 = ld4(a.b12 + ncol), b13 = ld4(a.b13 + ncol);
@@ -381,7 +399,9 @@ static bool use_wt(int64_t T, bool edge) {
 
 int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
     if (mode == TM_MM_F16X2 && use_wt(T, true)) return launch_enc_edge_wt(e, e.W13l, P, hE, E_idx, T, st);
-    EdgeArgsB a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
+    const bool h2 = mode == TM_MM_F16X2;
+    EdgeArgsB a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T,
+                h2 ? tm_find_wimg(e.W11 + 128) : nullptr, h2 ? tm_find_wimg(e.W12) : nullptr, h2 ? tm_find_wimg(e.W13) : nullptr};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
     static const bool dma = [] { const char *e = getenv("TMPNN_SPLIT_DMA"); return e != nullptr && e[0] == '1'; }();
@@ -418,6 +438,7 @@ struct MsgArgsB {
     const float *mask;
     float *Ssum, *cnt;
     int T;
+    const char *img1, *img2;                // fragment images of W1e / W2 (f16x2 only) or null
 };
 
 template <typename SP, bool DEC>
@@ -558,8 +579,8 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
     WFragS<SP> w1[1][4], w2[1][4];
-    load_wfrag_split<SP, 4>(a.W1e, a.ld1, 16 * wv, 0, TM_H, w1[0], lane);
-    load_wfrag_split<SP, 4>(a.W2, TM_H, 16 * wv, 0, TM_H, w2[0], lane);
+    load_wfrag_auto<SP>(a.img1, a.W1e, a.ld1, wv, lane, w1[0]);
+    load_wfrag_auto<SP>(a.img2, a.W2, TM_H, wv, lane, w2[0]);
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
     const f4 bias2 = ld4(a.b2 + ncol);
 
@@ -829,7 +850,8 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
                      const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt,
                      hipStream_t st) {
     if (mode == TM_MM_F16X2 && use_wt(T, false)) return launch_msg_wt(dec, W1e, ld1, W2, b2, P, hE, E_idx, mask, T, Ssum, cnt, st);
-    MsgArgsB a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T};
+    const bool h2 = mode == TM_MM_F16X2;
+    MsgArgsB a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T, h2 ? tm_find_wimg(W1e) : nullptr, h2 ? tm_find_wimg(W2) : nullptr};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
     if (mode == TM_MM_BF16X3) {
