@@ -19,11 +19,6 @@ extern "C" {
  * into the caller's arrays (up to `capacity` rows, names are static strings), clears the recording and
  * returns the number of rows (or a negative error). */
 int tmpnn_profile_enable(int on);
-/* Timing experiments only: launches the encoder edge-update kernel by itself with parts disabled
- * (ablation bitmask 1 no global loads, 2 no GELU, 4 no LayerNorm/store, 8 no MFMA; 0 = the real kernel).
- * Results are meaningless for ablation != 0. */
-int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const float *P, float *h_E, const int32_t *E_idx,
-                          int64_t T, int ablation, tmpnn_stream_t stream);
 int tmpnn_profile_fetch(const char **names, double *total_ms, int64_t *launches, int capacity);
 
 /* GEMM core probe: Y[t] = reps x (X[t] W^T) for T tiles of [48,128] and one [128,128] weight; mode 0 = exact fp32 MFMA,

@@ -389,31 +389,6 @@ def test_sharded_scan_single_rank_ragged(engine):
     assert torch.equal(tables[5], single)
 
 
-def test_enc_edge_kernel_variants_agree(engine):
-    """The experimental edge-update kernels (ping-pong, 8-wavefront, 2-workgroups-per-CU; selectable through the
-    measurement hook tmpnn_ablate_enc_edge) compute the same function as the shipped kernel."""
-    from thermompnn_amd import _lib
-    from thermompnn_amd.engine import _ptr, _stream
-    lib = _lib.load()
-    T = 777                                                    # not a multiple of anything: odd tile counts per workgroup
-    g = torch.Generator().manual_seed(3)
-    P = torch.randn(T, 256, generator=g).cuda()
-    hE = torch.randn(T, 48, 128, generator=g).cuda()
-    E_idx = torch.randint(0, T, (T, 48), generator=g).int()
-    E_idx[5, 40:] = -1                                         # invalid slots keep their (zero) rows
-    E_idx = E_idx.cuda()
-    hE[5, 40:] = 0
-    outs = {}
-    for code in (0, 16, 32, 64):
-        x = hE.clone()
-        assert lib.tmpnn_ablate_enc_edge(engine.w.handle, 1, _ptr(P), _ptr(x), _ptr(E_idx), T, code, _stream()) == 0
-        torch.cuda.synchronize()
-        outs[code] = x.cpu()
-    assert torch.equal(outs[0], outs[16]) and torch.equal(outs[0], outs[64])
-    assert (outs[0] - outs[32]).abs().max() < 1e-5             # different LayerNorm-statistics merge order
-    assert (outs[0][5, 40:] == 0).all()
-
-
 def test_centrality_and_baseline_and_scan(tmp_path, engine, synthetic_weights):
     """compute_centrality, ProteinMPNNBaseline, the many-PDB SSM driver."""
     from oracle import thermompnn_oracle as orc
@@ -558,12 +533,8 @@ def test_precision_default_comes_from_the_environment():
     assert bad.returncode != 0 and "unknown precision" in bad.stderr      # an error, not an abort()
 
 
-@pytest.mark.parametrize("env", [{"TMPNN_MSG_WAVES": "4"}, {"TMPNN_MSG_WAVES": "8"}, {"TMPNN_SPLIT_DMA": "1"},
-                                 {"TMPNN_NODE_SPLIT": "0", "TMPNN_FEAT_SPLIT": "0", "TMPNN_HEAD_SPLIT": "0"}, {"TMPNN_NODE_WAVES": "4"},
-                                 {"TMPNN_WT": "1", "TMPNN_WT_MIN_T": "0"}, {"TMPNN_WT": "1", "TMPNN_WT_MIN_T": "0", "TMPNN_WT_EDGE": "1"},
-                                 {"TMPNN_WT": "1", "TMPNN_WT_MIN_T": "0", "TMPNN_WT_EDGE": "1", "TMPNN_WT_WAVES": "12"}],
-                         ids=["msg4", "msg8", "dma_staging", "fp32_node_featurizer_head", "node4", "wt_msg", "wt_msg_edge",
-                              "wt_12_waves"])
+@pytest.mark.parametrize("env", [{"TMPNN_NODE_SPLIT": "0", "TMPNN_FEAT_SPLIT": "0", "TMPNN_HEAD_SPLIT": "0"}, {"TMPNN_NODE_IMG": "0"}],
+                         ids=["fp32_node_featurizer_head", "no_weight_fragment_images"])
 def test_selectable_kernel_forms_pass_golden_parity(env):
     """The non-default kernel forms of the f16x2 mode (selected by environment, read once per process) stay parity-green."""
     import subprocess

@@ -61,7 +61,6 @@ DEBUG_SIGNATURES = {
     "tmpnn_profile_fetch": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), _i]),
     "tmpnn_gemm_probe": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
     "tmpnn_clock_probe": (_i, [_i, _i, _p, _p, _p]),
-    "tmpnn_ablate_enc_edge": (_i, [_p, _i, _p, _p, _p, _i64, _i, _p]),
 }
 PRECISIONS = ("f16x2", "bf16x3", "fp32")
 STATUS_RANGE, STATUS_MAXLEN = 1, 2

@@ -199,10 +199,9 @@ extern "C" int64_t tmpnn_tensor_numel(int i) {
 }
 
 static const size_t POS_TABLE_FLOATS = 66 * TMPNN_HID, SEQ_TABLE_FLOATS = TMPNN_VOCAB * TMPNN_HID,
-                    CONV_CENTER_FLOATS = 384 * 384, W13L_BYTES = 32768;
+                    CONV_CENTER_FLOATS = 384 * 384;
 extern "C" size_t tmpnn_weights_packed_bytes(void) {
-    return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float) + 3 * W13L_BYTES +
-           (size_t)TM_N_WIMG * TM_WIMG_BYTES;
+    return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float) + (size_t)TM_N_WIMG * TM_WIMG_BYTES;
 }
 
 extern "C" int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *tensors, int n_tensors, void *packed,
@@ -289,11 +288,9 @@ extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const 
     w->pos_table = p; p += POS_TABLE_FLOATS;
     for (int l = 0; l < 3; ++l) { w->seq_table[l] = p; p += SEQ_TABLE_FLOATS; }
     w->conv_center = p; p += CONV_CENTER_FLOATS;
-    for (int l = 0; l < 3; ++l) w->enc[l].W13l = (const char *)p + (size_t)l * W13L_BYTES;
     int rc = launch_prep_tables(w, (hipStream_t)stream);
-    for (int l = 0; l < 3 && rc == TMPNN_OK; ++l) rc = launch_wt_prep(w->enc[l].W13, (char *)w->enc[l].W13l, (hipStream_t)stream);
     {   // fragment images of every 128 x 128 block the node kernels multiply by (see WImg)
-        char *img = (char *)p + 3 * W13L_BYTES;
+        char *img = (char *)p;
         auto add = [&](const float *base, int ld) {
             if (rc != TMPNN_OK || w->n_wimg >= TM_N_WIMG) return;
             w->wimg[w->n_wimg++] = WImg{base, img};
@@ -472,14 +469,6 @@ extern "C" int tmpnn_enc_layer(const tmpnn_weights_t *w, int layer, float *h_V, 
     LayerWs ws;
     TRY(carve_layer_ws(workspace, workspace_bytes, T, &ws));
     return run_enc_layer(w, layer, h_V, h_E, E_idx, mask, T, ws, false, nullptr, (hipStream_t)stream);
-}
-
-// measurement hook (tools/ablate.py): the encoder edge-update kernel alone, with parts switched off
-extern "C" int tmpnn_ablate_enc_edge(const tmpnn_weights_t *w, int layer, const float *P, float *h_E, const int32_t *E_idx,
-                                     int64_t T, int ablation, tmpnn_stream_t stream) {
-    REQUIRE(w && P && h_E && E_idx && layer >= 0 && layer < 3 && T > 0 && T <= T_MAX, "ablate_enc_edge: bad argument");
-    const TmModeScope scope(w);
-    return launch_enc_edge(w->enc[layer], P, h_E, E_idx, T, (hipStream_t)stream, ablation);
 }
 
 // measurement hook (tools/gemm_probe.py): one [48x128] x [128x128]^T GEMM per tile, mode 0 = fp32 MFMA, 1 = bf16x3 six-term, 2 = f16x2 three-term

@@ -9,7 +9,6 @@ struct EncW {   // device pointers into the raw state-dict tensors of one EncLay
     const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b;
     const float *W1, *b1, *W2, *b2, *W3, *b3, *W11, *b11, *W12, *b12, *W13, *b13;
     const float *Win, *bin, *Wout, *bout;
-    const char *W13l;      // derived: MFMA A-fragment image of the fp16 residual plane of W13 (tmpnn_wt.hip), 32 KB
 };
 struct DecW {
     const float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
@@ -89,7 +88,7 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
                        const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,
                        float *h_out, const NodeProj *p0, const NodeProj *p1, hipStream_t st);
-int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st, int abl = -1);   // -1 = shipped variant
+int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
 
 // tmpnn_head.hip
 int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg,
@@ -104,12 +103,6 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                      const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt, hipStream_t st);
 int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, hipStream_t st);
-
-// tmpnn_wt.hip: wave-owns-tile forms of the per-edge kernels (f16x2)
-int launch_wt_prep(const float *W13, char *dst_lplane, hipStream_t st);
-int launch_msg_wt(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P, const float *hE,
-                  const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt, hipStream_t st);
-int launch_enc_edge_wt(const EncW &e, const char *W13l, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
 
 int tm_num_cus();
 // matrix-core path of the per-edge GEMMs (tmpnn_split.h): a property of the weight handle (tmpnn_weights_create_p);

@@ -207,267 +207,6 @@ struct EdgeArgs {
     int T;
 };
 
-// Row statistics for LayerNorm computed where the values already sit in registers (MFMA D layout: a lane
-// holds 8 of the 128 columns of its row, 2 blocks x 4): per-lane mean/M2, Chan-merged across the 4 q-lanes
-// with two shuffles, one (mean, M2) pair per wavefront and row left in LDS; the row phase merges the 4
-// wavefront partials. Numerically a two-pass variance (no E[x^2]-mean^2 cancellation).
-__device__ __forceinline__ void row_stats_partial(const f4 (&v)[2], float *stat_slot /* &s_stat[row][wave][0] */, int q) {
-    float mean = (v[0].x + v[0].y + v[0].z + v[0].w + v[1].x + v[1].y + v[1].z + v[1].w) * 0.125f;
-    float m2 = 0.f;
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const f4 d = v[cb] - mean;
-        m2 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
-    }
-    float n = 8.f;
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {          // merge equal-sized groups: q ^ 1, then q ^ 2
-        const float mo = __shfl_xor(mean, off), m2o = __shfl_xor(m2, off);
-        const float delta = mo - mean;
-        mean = 0.5f * (mean + mo);
-        m2 = m2 + m2o + delta * delta * (0.5f * n);
-        n *= 2.f;
-    }
-    if (q == 0) { stat_slot[0] = mean; stat_slot[1] = m2; }
-}
-
-// merge the four per-wavefront (mean, M2) partials (32 columns each) of one row -> (mean, rstd)
-__device__ __forceinline__ void row_stats_finish(const float *stat_row /* 8 floats */, float &mean, float &rstd) {
-    const f4 a = ld4(stat_row), b = ld4(stat_row + 4);      // (mean0, m2_0, mean1, m2_1), (mean2, m2_2, mean3, m2_3)
-    mean = 0.25f * (a.x + a.z + b.x + b.z);
-    const float d0 = a.x - mean, d1 = a.z - mean, d2 = b.x - mean, d3 = b.z - mean;
-    const float m2 = a.y + a.w + b.y + b.w + 32.f * (d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
-    rstd = 1.0f / sqrtf(m2 * (1.0f / 128.0f) + 1e-5f);
-}
-
-// ABL = ablation bitmask for tools/ablate.py (0 in the product): 1 no global loads, 2 no GELU, 4 no LN/store, 8 no MFMA
-//
-// Software pipeline (1 workgroup per CU, 192 weight VGPRs): at the top of an iteration the NEXT residue's edge
-// tile is requested by LDS-DMA into the other half of a double-buffered tE and its neighbour list is read; its
-// gathered node rows are requested right after the first barrier and only consumed in the next iteration.
-// HBM/L2 latency is hidden under the three GEMMs.
-template <int ABL>
-__global__ __launch_bounds__(TM_THREADS, 1) void enc_edge_kernel(EdgeArgs a) {
-    __shared__ __attribute__((aligned(16))) float tE[2][TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][8];
-    __shared__ int s_idx[2][TM_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-
-    float w11[2][32], w12[2][32], w13[2][32];
-    f4 b12[2], b13[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int n0 = 32 * wv + 16 * cb;
-        load_wfrag<8>(a.W11e, 384, n0, 0, TM_H, w11[cb], lane);
-        load_wfrag<8>(a.W12, TM_H, n0, 0, TM_H, w12[cb], lane);
-        load_wfrag<8>(a.W13, TM_H, n0, 0, TM_H, w13[cb], lane);
-        b12[cb] = ld4(a.b12 + n0 + 4 * q);
-        b13[cb] = ld4(a.b13 + n0 + 4 * q);
-    }
-    const int c32 = lane & 31;
-    const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
-    const int ncol = 32 * wv + 4 * q;                     // this lane's first column (block 0); block 1 = +16
-
-    const TileRange tr = xcd_tile_range(a.T);
-    int i = tr.begin;
-    int cur = 0;
-    f4 gai[2], gcj[3][2];                                 // A'_i and C'_j rows of the tile about to be processed
-    if (i < tr.end) {                                     // prologue: first tile
-        if (tid < TM_TILE) s_idx[0][tid] = a.E_idx[(size_t)i * TM_KS + tid];
-        if (!(ABL & 1)) load_tile_async(tE[0], a.hE + (size_t)i * TM_KS * TM_H, wv, lane);
-        __syncthreads();
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            gai[cb] = (ABL & 1) ? b12[cb] : ld4(a.P + (size_t)i * 256 + ncol + 16 * cb);
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) {
-                const int j = s_idx[0][16 * rb + m];
-                gcj[rb][cb] = (ABL & 1) ? b13[cb] : ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol + 16 * cb);
-            }
-        }
-    }
-
-    for (; i < tr.end; i += tr.step) {
-        float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
-        const float *tEc = tE[cur];
-        const int inext = i + tr.step;
-        const bool has_next = inext < tr.end;
-        int nidx = -1;
-        if (has_next) {
-            if (!(ABL & 1)) load_tile_async(tE[cur ^ 1], a.hE + (size_t)inext * TM_KS * TM_H, wv, lane);
-            if (tid < TM_TILE) nidx = a.E_idx[(size_t)inext * TM_KS + tid];
-        }
-
-        f4 acc[3][2];
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = gai[cb] + gcj[rb][cb];
-        if (!(ABL & 8)) mma_tile<8, 2>(tEc, w11, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-                st4(tA + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), (ABL & 2) ? acc[rb][cb] : gelu4(acc[rb][cb]));
-        if (has_next && tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx;
-        __syncthreads();
-
-        if (has_next) {                                        // request the next tile's node rows (used next iteration)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                gai[cb] = (ABL & 1) ? b12[cb] : ld4(a.P + (size_t)inext * 256 + ncol + 16 * cb);
-#pragma unroll
-                for (int rb = 0; rb < 3; ++rb) {
-                    const int j = s_idx[cur ^ 1][16 * rb + m];
-                    gcj[rb][cb] = (ABL & 1) ? b13[cb] : ld4(a.P + (size_t)(j < 0 ? inext : j) * 256 + 128 + ncol + 16 * cb);
-                }
-            }
-        }
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = b12[cb];
-        if (!(ABL & 8)) mma_tile<8, 2>(tA, w12, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-                st4(tB + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), (ABL & 2) ? acc[rb][cb] : gelu4(acc[rb][cb]));
-        __syncthreads();
-
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = b13[cb];
-        if (!(ABL & 8)) mma_tile<8, 2>(tB, w13, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            f4 v[2];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int off = chunk_off(16 * rb + m, 8 * wv + 4 * cb + q);
-                v[cb] = ld4(tEc + off) + acc[rb][cb];          // residual
-                st4(tA + off, v[cb]);
-            }
-            if (!(ABL & 4)) row_stats_partial(v, &s_stat[16 * rb + m][2 * wv], q);
-        }
-        __syncthreads();
-
-        // row phase: half-wavefront per edge row: normalise + coalesced 512-byte stores
-        if (!(ABL & 4)) {
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int row = 12 * wv + 2 * it + (lane >> 5);
-                float mean, rstd;
-                row_stats_finish(&s_stat[row][0], mean, rstd);
-                const f4 y = (ld4(tA + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
-                if (s_idx[cur][row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
-            }
-        } else if (tA[tid] == 123.456f) tile_g[tid] = 1.f;    // keep the ablated pipeline live
-        cur ^= 1;
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// enc_edge, two-workgroups-per-CU form: same arithmetic as enc_edge_kernel<0>, trimmed to <= 256 VGPRs (192 of them
-// weights) and 74 KB of LDS so that TWO workgroups share a CU and one's GELU / LayerNorm / load phases run under the
-// other's GEMMs (cross-wavefront MFMA/VALU overlap works, same-wavefront does not: tools/probe/overlap_probe.hip).
-// No register prefetch: biases, LayerNorm parameters and gathered rows are (re)loaded at their point of use.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TM_THREADS, 2) void enc_edge2_kernel(EdgeArgs a) {
-    __shared__ __attribute__((aligned(16))) float tE[TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][8];
-    __shared__ int s_idx[TM_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-
-    float w11[2][32], w12[2][32], w13[2][32];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int n0 = 32 * wv + 16 * cb;
-        load_wfrag<8>(a.W11e, 384, n0, 0, TM_H, w11[cb], lane);
-        load_wfrag<8>(a.W12, TM_H, n0, 0, TM_H, w12[cb], lane);
-        load_wfrag<8>(a.W13, TM_H, n0, 0, TM_H, w13[cb], lane);
-    }
-    const int c32 = lane & 31;
-    const int ncol = 32 * wv + 4 * q;
-
-    const TileRange tr = xcd_tile_range(a.T);
-    for (int i = tr.begin; i < tr.end; i += tr.step) {
-        float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
-        if (tid < TM_TILE) s_idx[tid] = a.E_idx[(size_t)i * TM_KS + tid];
-        load_tile_async(tE, tile_g, wv, lane);
-        __syncthreads();
-
-        f4 acc[3][2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const f4 ai = ld4(a.P + (size_t)i * 256 + ncol + 16 * cb);
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) {
-                const int j = s_idx[16 * rb + m];
-                acc[rb][cb] = ai + ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol + 16 * cb);
-            }
-        }
-        mma_tile<8, 2>(tE, w11, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) st4(tA + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(acc[rb][cb]));
-        __syncthreads();
-
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const f4 b = ld4(a.b12 + ncol + 16 * cb);
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = b;
-        }
-        mma_tile<8, 2>(tA, w12, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) st4(tB + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(acc[rb][cb]));
-        __syncthreads();
-
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const f4 b = ld4(a.b13 + ncol + 16 * cb);
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) acc[rb][cb] = b;
-        }
-        mma_tile<8, 2>(tB, w13, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            f4 v[2];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int off = chunk_off(16 * rb + m, 8 * wv + 4 * cb + q);
-                v[cb] = ld4(tE + off) + acc[rb][cb];
-                st4(tA + off, v[cb]);
-            }
-            row_stats_partial(v, &s_stat[16 * rb + m][2 * wv], q);
-        }
-        __syncthreads();
-
-        {
-            const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int row = 12 * wv + 2 * it + (lane >> 5);
-                float mean, rstd;
-                row_stats_finish(&s_stat[row][0], mean, rstd);
-                const f4 y = (ld4(tA + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
-                if (s_idx[row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // enc_edge, 8-wavefront form: 512 threads, wavefront w owns ONE 16-column block (96 weight VGPRs instead of 192), so
 // two wavefronts share each SIMD: the matrix pipe sees the same 192 MFMAs per GEMM per SIMD, but their issue, the
@@ -592,198 +331,6 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_kernel(EdgeArgs a) {
             if (s_idx[cur][row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
         }
         cur ^= 1;
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// enc_edge, ping-pong form: TWO residues (streams A and B) are in flight per workgroup, skewed by one stage, so
-// every barrier interval pairs a GEMM of one tile (matrix pipe) with the GELU / residual / LayerNorm-store work
-// of the other (VALU, LDS, global stores), interleaved at k-step granularity by mma_tile_with():
-//     J1 V1(A)|M1(B)  J2 M2(A)|V1(B)  J3 V2(A)|M2(B)  J4 M3(A)|V2(B)  J5 V3(A)|M3(B)  J6 S(A),V3(B)  J7 M1(A')|S(B)
-// Each tile owns three LDS buffers (e, x, y); the next tile of a stream is DMA-ed into the y buffer as soon as
-// its GEMM3 has consumed it and the roles rotate (e,x,y) <- (y,x,e). 6 x 24 KB of LDS, 7 barriers per pair.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TM_THREADS, 1) void enc_edge_pp_kernel(EdgeArgs a) {
-    __shared__ __attribute__((aligned(16))) float tiles[6][TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) float s_stat[2][TM_TILE][8];
-    __shared__ int s_idx[2][2][TM_TILE];                       // [stream][parity][slot]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-
-    float w11[2][32], w12[2][32], w13[2][32];
-    f4 b12[2], b13[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int n0 = 32 * wv + 16 * cb;
-        load_wfrag<8>(a.W11e, 384, n0, 0, TM_H, w11[cb], lane);
-        load_wfrag<8>(a.W12, TM_H, n0, 0, TM_H, w12[cb], lane);
-        load_wfrag<8>(a.W13, TM_H, n0, 0, TM_H, w13[cb], lane);
-        b12[cb] = ld4(a.b12 + n0 + 4 * q);
-        b13[cb] = ld4(a.b13 + n0 + 4 * q);
-    }
-    const int c32 = lane & 31;
-    const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
-    const int ncol = 32 * wv + 4 * q;
-
-    const TileRange tr = xcd_tile_range(a.T);
-    if (tr.begin >= tr.end) return;
-    const int n = (tr.end - tr.begin + tr.step - 1) / tr.step;   // tiles of this workgroup
-    const int npairs = (n + 1) >> 1;
-    auto tile_of = [&](int k) { return tr.begin + (k < n ? k : n - 1) * tr.step; };
-
-    int be[2] = {0, 3}, bx[2] = {1, 4}, by[2] = {2, 5};
-    int par = 0;
-    f4 gai[2][2], gcj[2][3][2];                                // [stream]: A'_i and C'_j rows (acc init of GEMM1)
-    f4 accA[3][2], accB[3][2];
-
-    auto gather = [&](int s, int i, int parity) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            gai[s][cb] = ld4(a.P + (size_t)i * 256 + ncol + 16 * cb);
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) {
-                const int j = s_idx[s][parity][16 * rb + m];
-                gcj[s][rb][cb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol + 16 * cb);
-            }
-        }
-    };
-    // V1 / V2: block k of the GELU epilogue (k = 2 rb + cb)
-    auto gelu_block = [&](f4 (&acc)[3][2], float *dst, int k) {
-        if (k < 6) {
-            const int rb = k >> 1, cb = k & 1;
-            st4(dst + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), gelu4(acc[rb][cb]));
-        }
-    };
-    // V3: residual + LayerNorm partial statistics of row block k
-    auto resid_block = [&](f4 (&acc)[3][2], const float *e, float *dst, int s, int k) {
-        if (k < 3) {
-            f4 v[2];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int off = chunk_off(16 * k + m, 8 * wv + 4 * cb + q);
-                v[cb] = ld4(e + off) + acc[k][cb];
-                st4(dst + off, v[cb]);
-            }
-            row_stats_partial(v, &s_stat[s][16 * k + m][2 * wv], q);
-        }
-    };
-    // S: normalise + store two rows (iteration k of 6)
-    auto store_rows = [&](const float *x, int s, int parity, float *tile_g, bool valid, int k) {
-        if (k < 6) {
-            const int row = 12 * wv + 2 * k + (lane >> 5);
-            float mean, rstd;
-            row_stats_finish(&s_stat[s][row][0], mean, rstd);
-            const f4 y = (ld4(x + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
-            if (valid && s_idx[s][parity][row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
-        }
-    };
-
-    // ---- prologue: first pair in, GEMM1 of A ----
-    {
-        const int iA = tile_of(0), iB = tile_of(1);
-        if (tid < TM_TILE) {
-            s_idx[0][0][tid] = a.E_idx[(size_t)iA * TM_KS + tid];
-            s_idx[1][0][tid] = a.E_idx[(size_t)iB * TM_KS + tid];
-        }
-        load_tile_async(tiles[be[0]], a.hE + (size_t)iA * TM_KS * TM_H, wv, lane);
-        load_tile_async(tiles[be[1]], a.hE + (size_t)iB * TM_KS * TM_H, wv, lane);
-        __syncthreads();
-        gather(0, iA, 0);
-        gather(1, iB, 0);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) accA[rb][cb] = gai[0][cb] + gcj[0][rb][cb];
-        mma_tile<8, 2>(tiles[be[0]], w11, accA, lane);
-    }
-
-    for (int p = 0; p < npairs; ++p) {
-        const int iA = tile_of(2 * p), iB = tile_of(2 * p + 1);
-        const bool vB = 2 * p + 1 < n;
-        const bool has_next = p + 1 < npairs;
-        const int iA2 = tile_of(2 * p + 2), iB2 = tile_of(2 * p + 3);
-        float *gA = a.hE + (size_t)iA * TM_KS * TM_H, *gB = a.hE + (size_t)iB * TM_KS * TM_H;
-
-        // J1: V1(A) | M1(B)
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) accB[rb][cb] = gai[1][cb] + gcj[1][rb][cb];
-        mma_tile_with<8, 2>(tiles[be[1]], w11, accB, lane, [&](int kk) { gelu_block(accA, tiles[bx[0]], kk); });
-        __syncthreads();
-
-        // J2: M2(A) | V1(B)       (+ next pair's neighbour lists -> registers)
-        int nidxA = -1, nidxB = -1;
-        if (has_next && tid < TM_TILE) {
-            nidxA = a.E_idx[(size_t)iA2 * TM_KS + tid];
-            nidxB = a.E_idx[(size_t)iB2 * TM_KS + tid];
-        }
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) accA[rb][cb] = b12[cb];
-        mma_tile_with<8, 2>(tiles[bx[0]], w12, accA, lane, [&](int kk) { gelu_block(accB, tiles[bx[1]], kk); });
-        __syncthreads();
-
-        // J3: V2(A) | M2(B)
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) accB[rb][cb] = b12[cb];
-        mma_tile_with<8, 2>(tiles[bx[1]], w12, accB, lane, [&](int kk) { gelu_block(accA, tiles[by[0]], kk); });
-        __syncthreads();
-
-        // J4: M3(A) | V2(B)       (+ publish the next pair's neighbour lists)
-        if (has_next && tid < TM_TILE) {
-            s_idx[0][par ^ 1][tid] = nidxA;
-            s_idx[1][par ^ 1][tid] = nidxB;
-        }
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) accA[rb][cb] = b13[cb];
-        mma_tile_with<8, 2>(tiles[by[0]], w13, accA, lane, [&](int kk) { gelu_block(accB, tiles[by[1]], kk); });
-        __syncthreads();
-
-        // J5: V3(A) | M3(B)       (+ DMA of A' into y_A, request A' node rows)
-        if (has_next) {
-            load_tile_async(tiles[by[0]], a.hE + (size_t)iA2 * TM_KS * TM_H, wv, lane);
-            gather(0, iA2, par ^ 1);
-        }
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) accB[rb][cb] = b13[cb];
-        mma_tile_with<8, 2>(tiles[by[1]], w13, accB, lane,
-                            [&](int kk) { resid_block(accA, tiles[be[0]], tiles[bx[0]], 0, kk); });
-        __syncthreads();
-
-        // J6: S(A), V3(B)         (+ DMA of B' into y_B, request B' node rows)
-        if (has_next) {
-            load_tile_async(tiles[by[1]], a.hE + (size_t)iB2 * TM_KS * TM_H, wv, lane);
-            gather(1, iB2, par ^ 1);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) resid_block(accB, tiles[be[1]], tiles[bx[1]], 1, k);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) store_rows(tiles[bx[0]], 0, par, gA, true, k);
-        __syncthreads();
-
-        // J7: M1(A') | S(B)       rotate A: (e, x, y) <- (y, x, e)
-        { const int t = be[0]; be[0] = by[0]; by[0] = t; }
-        if (has_next) {
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) accA[rb][cb] = gai[0][cb] + gcj[0][rb][cb];
-            mma_tile_with<8, 2>(tiles[be[0]], w11, accA, lane,
-                                [&](int kk) { store_rows(tiles[bx[1]], 1, par, gB, vB, kk); });
-        } else {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) store_rows(tiles[bx[1]], 1, par, gB, vB, k);
-        }
-        { const int t = be[1]; be[1] = by[1]; by[1] = t; }
-        par ^= 1;
         __syncthreads();
     }
 }
@@ -961,67 +508,30 @@ int launch_node_proj(const float *h, const NodeProj &np, int64_t T, hipStream_t 
 
 int launch_msg(bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt, hipStream_t st) {
-    MsgArgs a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T, 0};
-    static const int nw = [] { const char *e = getenv("TMPNN_MSG_WAVES"); return e ? atoi(e) : 4; }();
-    const int grid = grid_for(T, 2);
     tm_prof_begin(dec ? "dec_msg" : "enc_msg", st);
     if (tm_matmul_mode() != TM_MM_FP32) {
         const int rc = launch_msg_split(tm_matmul_mode(), dec, W1e, ld1, W2, b2, P, hE, E_idx, mask, T, Ssum, cnt, st);
         tm_prof_end(st);
         return rc;
     }
-    if (nw == 8) {
-        if (dec) msg_kernel<true, 8><<<grid, 512, 0, st>>>(a);
-        else msg_kernel<false, 8><<<grid, 512, 0, st>>>(a);
-    } else {
-        if (dec) msg_kernel<true, 4><<<grid, 256, 0, st>>>(a);
-        else msg_kernel<false, 4><<<grid, 256, 0, st>>>(a);
-    }
+    MsgArgs a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T, 0};
+    if (dec) msg_kernel<true, 4><<<grid_for(T, 2), 256, 0, st>>>(a);
+    else msg_kernel<false, 4><<<grid_for(T, 2), 256, 0, st>>>(a);
     tm_prof_end(st);
     return tm_check_launch(dec ? "dec_msg" : "enc_msg");
 }
 
-int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st, int abl) {
-    EdgeArgs a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
-    const int grid = grid_for(T, 1);
+int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
     tm_prof_begin("enc_edge", st);
-    // Shipped form = the 8-wavefront kernel (code 32; 6 % faster than the 4-wavefront one on MI355X). The others stay
-    // selectable for experiments: TMPNN_ENC_EDGE_VARIANT = 1 (4-wavefront), 16 (ping-pong), 64 (2 workgroups per CU),
-    // or the ablation codes of tmpnn_ablate_enc_edge (0 there means the 4-wavefront kernel).
-    static const int variant = [] { const char *e = getenv("TMPNN_ENC_EDGE_VARIANT"); return e ? atoi(e) : 32; }();
-    if (abl < 0) abl = tm_matmul_mode() != TM_MM_FP32 ? 128 : (variant == 1 ? 0 : variant);
-    if (abl == 128 || abl == 129) {      // split-precision 16-bit matrix-core forms (tmpnn_split.hip); 129 forces bf16x3
-        const int mode = abl == 129 || tm_matmul_mode() == TM_MM_BF16X3 ? TM_MM_BF16X3 : TM_MM_F16X2;
-        const int rc = launch_enc_edge_split(mode, e, P, hE, E_idx, T, st);
+    if (tm_matmul_mode() != TM_MM_FP32) {        // split-precision 16-bit matrix-core forms (tmpnn_split.hip)
+        const int rc = launch_enc_edge_split(tm_matmul_mode(), e, P, hE, E_idx, T, st);
         tm_prof_end(st);
         return rc;
     }
-    if (abl == 64) {
-        enc_edge2_kernel<<<grid_for(T, 2), TM_THREADS, 0, st>>>(a);
-        tm_prof_end(st);
-        return tm_check_launch("enc_edge2");
-    }
-    if (abl == 32) {
-        enc_edge8_kernel<<<grid, 512, 0, st>>>(a);
-        tm_prof_end(st);
-        return tm_check_launch("enc_edge8");
-    }
-    if (abl == 16) {
-        enc_edge_pp_kernel<<<grid, TM_THREADS, 0, st>>>(a);
-        tm_prof_end(st);
-        return tm_check_launch("enc_edge_pp");
-    }
-    switch (abl) {
-        case 0: enc_edge_kernel<0><<<grid, TM_THREADS, 0, st>>>(a); break;
-        case 1: enc_edge_kernel<1><<<grid, TM_THREADS, 0, st>>>(a); break;
-        case 2: enc_edge_kernel<2><<<grid, TM_THREADS, 0, st>>>(a); break;
-        case 4: enc_edge_kernel<4><<<grid, TM_THREADS, 0, st>>>(a); break;
-        case 7: enc_edge_kernel<7><<<grid, TM_THREADS, 0, st>>>(a); break;
-        case 8: enc_edge_kernel<8><<<grid, TM_THREADS, 0, st>>>(a); break;
-        default: return tm_set_error(TMPNN_E_INVALID, "enc_edge: unknown ablation %d", abl);
-    }
+    EdgeArgs a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T};
+    enc_edge8_kernel<<<grid_for(T, 1), 512, 0, st>>>(a);
     tm_prof_end(st);
-    return tm_check_launch("enc_edge");
+    return tm_check_launch("enc_edge8");
 }
 
 int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,

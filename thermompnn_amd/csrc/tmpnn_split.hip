@@ -384,29 +384,13 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     }
 }
 
-// Wave-owns-tile forms (tmpnn_wt.hip) for batches that give every wavefront of the chip work; the workgroup-per-tile
-// forms below are the shipped path. Measured on MI355X (64 x L=256): message pass 0.221-0.225 ms against 0.230-0.234 ms,
-// edge update 0.42 vs 0.345 ms (its third weight does not fit LDS). A 4 % gain on one kernel family does not pay for
-// results that depend on the batch size in the last bits (the two forms round differently, and the choice would follow
-// T), so they are OPT-IN experiments: TMPNN_WT=1 enables the message kernels, TMPNN_WT_EDGE=1 the edge kernel as well,
-// TMPNN_WT_MIN_T moves the switch-over. DESIGN.md §7 has the ablation data.
-static bool use_wt(int64_t T, bool edge) {
-    static const int on = [] { const char *e = getenv("TMPNN_WT"); return e ? atoi(e) : 0; }();
-    static const int on_edge = [] { const char *e = getenv("TMPNN_WT_EDGE"); return e ? atoi(e) : 0; }();
-    static const int64_t min_t = [] { const char *e = getenv("TMPNN_WT_MIN_T"); return e ? atoll(e) : 2048; }();
-    return on != 0 && (!edge || on_edge != 0) && T >= min_t;
-}
-
 int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
-    if (mode == TM_MM_F16X2 && use_wt(T, true)) return launch_enc_edge_wt(e, e.W13l, P, hE, E_idx, T, st);
     const bool h2 = mode == TM_MM_F16X2;
     EdgeArgsB a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T,
                 h2 ? tm_find_wimg(e.W11 + 128) : nullptr, h2 ? tm_find_wimg(e.W12) : nullptr, h2 ? tm_find_wimg(e.W13) : nullptr};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
-    static const bool dma = [] { const char *e = getenv("TMPNN_SPLIT_DMA"); return e != nullptr && e[0] == '1'; }();
     if (mode == TM_MM_BF16X3) enc_edge8_split_kernel<SplitBF3><<<grid, 512, 0, st>>>(a);
-    else if (dma) enc_edge8_split_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
     else {
         static const bool prof = [] { const char *e = getenv("TMPNN_EDGE_PROF"); return e != nullptr && e[0] == '1'; }();
         if (prof) {                                  // debug: phase timing of workgroup 0 (synchronises!)
@@ -702,336 +686,31 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     }
 }
 
-// 4-wavefront form (f16x2): each wavefront owns 32 output columns (two column blocks, 128 weight VGPRs), one row
-// block in flight at a time; two workgroups share a CU, so one workgroup's GELU/split (VALU) phases run under the
-// other's MFMA phases — a wavefront cannot overlap the two by itself — and every B-fragment read feeds two MFMA chains.
-// The next residue's fp32 tile lands in an LDS staging buffer by (inline-asm) LDS-DMA under GEMM 1. The masked sum over
-// the K neighbours is taken in registers (row blocks added per lane, then a 16-lane butterfly), so there is no fp32
-// message tile, no aggregation phase and only two barriers per residue.
-template <typename SP, bool DEC>
-__global__ __launch_bounds__(256, 2) void msg4_rp_kernel(MsgArgsB a) {
-    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
-    __shared__ __attribute__((aligned(16))) char tE[TILEB];
-    __shared__ __attribute__((aligned(16))) char tA[TILEB];
-    __shared__ __attribute__((aligned(16))) float tStage[TM_TILE * TM_H];
-    __shared__ int s_idx[2][TM_TILE];
-    __shared__ float s_ma[2][TM_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-
-    WFragS<SP> w1[2][4], w2[2][4];
-    f4 bias2[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        load_wfrag_split<SP, 4>(a.W1e, a.ld1, 32 * wv + 16 * cb, 0, TM_H, w1[cb], lane);
-        load_wfrag_split<SP, 4>(a.W2, TM_H, 32 * wv + 16 * cb, 0, TM_H, w2[cb], lane);
-        bias2[cb] = ld4(a.b2 + 32 * wv + 16 * cb + 4 * q);
-    }
-    const int ncol = 32 * wv + 4 * q, c4 = 8 * wv + q;      // column block cb adds 16 columns / 4 chunks
-
-    auto stage_idx = [&](int ii, int buf) {           // neighbour list + attention mask of residue ii -> LDS
-        if (tid < TM_TILE) {
-            const int j = a.E_idx[(size_t)ii * TM_KS + tid];
-            s_idx[buf][tid] = j;
-            s_ma[buf][tid] = j < 0 ? 0.f : (DEC ? 1.f : a.mask[ii] * a.mask[j]);
-        }
-    };
-    f4 g0[2], gj[3][2];
-    auto gather = [&](int ii, int buf) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) g0[cb] = ld4(a.P + (size_t)ii * 256 + ncol + 16 * cb);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const int j0 = s_idx[buf][16 * rb + m];
-            const int j = j0 < 0 ? ii : j0;
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                gj[rb][cb] = ld4(a.P + (size_t)j * 256 + 128 + ncol + 16 * cb);
-            }
-        }
-    };
-    auto stage_async = [&](int ii) {                  // linear copy of one fp32 tile: 24 x 1 KB, six per wavefront
-        const float *src = a.hE + (size_t)ii * TM_KS * TM_H;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int blk = 6 * wv + k;
-            lds_dma16(src + blk * 256 + lane * 4, tStage + blk * 256);
-        }
-    };
-    auto split_stage = [&]() {                        // tStage (fp32, linear) -> e planes
-#pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int idx = it * 256 + tid;
-            store_split<SP>(tE, idx >> 5, idx & 31, ld4(tStage + idx * 4));
-            if (it & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    const TileRange tr = xcd_tile_range(a.T);
-    int i = tr.begin;
-    int cur = 0;
-    if (i < tr.end) {
-        stage_idx(i, 0);
-        stage_async(i);
-        lds_dma_wait();
-        __syncthreads();
-        split_stage();
-        gather(i, 0);
-        __syncthreads();
-    }
-    for (; i < tr.end; i += tr.step) {
-        const int inext = i + tr.step;
-        const int ipf = inext < tr.end ? inext : i;             // the last iteration prefetches its own tile again
-        const float mi = a.mask[i];
-        // next residue: neighbour list first, then the tile copy; the list is published behind GEMM 1 and its dependent
-        // mask gather only at the end of the iteration — no wavefront waits on a global load in front of its MFMAs
-        int nidx = -1;
-        if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf * TM_KS + tid];
-        stage_async(ipf);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            f4 acc[2];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[cb] = DEC ? gj[rb][cb] : g0[cb] + gj[rb][cb];
-            mma_rb_split<SP, 4, 2>(tE, rb, w1, acc, lane);
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                f4 v = acc[cb];
-                if (DEC) v = g0[cb] + mi * v;
-                store_split<SP>(tA, 16 * rb + m, c4 + 4 * cb, gelu4(v));
-            }
-            __builtin_amdgcn_sched_barrier(0);                   // one row block at a time
-        }
-        lds_dma_wait();
-        float nma = 0.f;
-        if (tid < TM_TILE) {
-            s_idx[cur ^ 1][tid] = nidx;
-            if (nidx >= 0) nma = DEC ? 1.f : a.mask[ipf] * a.mask[nidx];
-        }
-        __syncthreads();                                         // tE consumed; tA, tStage, s_idx[next] complete
-
-        split_stage();
-        gather(ipf, cur ^ 1);
-        f4 tot[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            f4 acc[2] = {bias2[0], bias2[1]};
-            mma_rb_split<SP, 4, 2>(tA, rb, w2, acc, lane);
-            const float ma = s_ma[cur][16 * rb + m];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                f4 v = gelu4(acc[cb]) * ma;
-                if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
-                tot[cb] += v;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int off = 1; off <= 8; off <<= 1)                   // sum over the 16 rows of the lane group (fixed order)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) tot[cb][k] += __shfl_xor(tot[cb][k], off);
-        if (m == 0) {
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) st4(a.Ssum + (size_t)i * TM_H + ncol + 16 * cb, tot[cb]);
-        }
-        if (tid == 128) {                                        // neighbour count of this tile
-            float c = 0.f;
-            for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
-            a.cnt[i] = c;
-        }
-        if (tid < TM_TILE) s_ma[cur ^ 1][tid] = nma;
-        cur ^= 1;
-        __syncthreads();                                         // tA / tStage consumed, tE + s_ma[next] complete
-    }
-}
-
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                      const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt,
                      hipStream_t st) {
-    if (mode == TM_MM_F16X2 && use_wt(T, false)) return launch_msg_wt(dec, W1e, ld1, W2, b2, P, hE, E_idx, mask, T, Ssum, cnt, st);
     const bool h2 = mode == TM_MM_F16X2;
     MsgArgsB a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T, h2 ? tm_find_wimg(W1e) : nullptr, h2 ? tm_find_wimg(W2) : nullptr};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
-    if (mode == TM_MM_BF16X3) {
+    if (mode == TM_MM_BF16X3) {                      // staged through LDS (the exact three-plane tiles leave no VGPRs for a register prefetch)
         if (dec) msg8_split_kernel<SplitBF3, true><<<grid, 512, 0, st>>>(a);
         else msg8_split_kernel<SplitBF3, false><<<grid, 512, 0, st>>>(a);
     } else {
-        static const bool dma = [] { const char *e = getenv("TMPNN_SPLIT_DMA"); return e != nullptr && e[0] == '1'; }();
-        // measured on MI355X (same run, 64 x L=256): with its B-fragment reads pipelined (TM_MSG_PF) the 8-wavefront form
-        // runs 0.238 (enc) / 0.235 ms (dec) against 0.252 / 0.260 ms for the 4-wavefront form (TMPNN_MSG_WAVES=4)
-        static const int nw_env = [] { const char *e = getenv("TMPNN_MSG_WAVES"); return e ? atoi(e) : 0; }();
-        const int nw = nw_env ? nw_env : 8;
-        if (dma) {
-            if (dec) msg8_split_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
-            else msg8_split_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
-        } else if (nw == 8) {
-            static const bool prof = [] { const char *e = getenv("TMPNN_MSG_PROF"); return e != nullptr && e[0] == '1'; }();
-            if (prof && dec) {                       // debug: phase timing of workgroup 0 (synchronises!)
-                static unsigned long long *d_prof = nullptr;
-                if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
-                (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
-                msg8_rp_kernel<SplitH2, true, true><<<grid, 512, 0, st>>>(a, d_prof);
-                unsigned long long h[16];
-                (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
-                fprintf(stderr, "dec_msg phases (cycles, wg 0): fetch+gemm1 %llu gelu+split %llu bar %llu split_tile+gather %llu gemm2 %llu gelu+mask %llu bar %llu ksum+store %llu\n",
-                        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-            } else if (dec) msg8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
-            else msg8_rp_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
-        } else {
-            const int grid2 = (int)(T < 2 * cap ? T : 2 * cap);
-            if (dec) msg4_rp_kernel<SplitH2, true><<<grid2, 256, 0, st>>>(a);
-            else msg4_rp_kernel<SplitH2, false><<<grid2, 256, 0, st>>>(a);
-        }
+        static const bool prof = [] { const char *e = getenv("TMPNN_MSG_PROF"); return e != nullptr && e[0] == '1'; }();
+        if (prof && dec) {                           // debug: phase timing of workgroup 0 (synchronises!)
+            static unsigned long long *d_prof = nullptr;
+            if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
+            (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+            msg8_rp_kernel<SplitH2, true, true><<<grid, 512, 0, st>>>(a, d_prof);
+            unsigned long long h[16];
+            (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "dec_msg phases (cycles, wg 0): fetch+gemm1 %llu gelu+split %llu bar %llu split_tile+gather %llu gemm2 %llu gelu+mask %llu bar %llu ksum+store %llu\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        } else if (dec) msg8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
+        else msg8_rp_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
     }
     return tm_check_launch(dec ? "dec_msg_split" : "enc_msg_split");
-}
-
-// ------------------------------------------------------------------------------------------------
-// node_update, split-precision form (f16x2): same stages as node_update_kernel (tmpnn_layers.hip) — W3, LN1, FFN
-// 128 -> 512 -> 128 in four chunks, LN2, mask, up to two node projections — with every GEMM on the 16-bit matrix cores.
-// The weights still stream from L2 as fp32 and are split into fragments on the fly (96 VALU per 16 x 128 block: 5 % of a
-// tile's time, against 5x less matrix time); GEMM inputs are plane tiles, LayerNorm inputs fp32 tiles.
-// ------------------------------------------------------------------------------------------------
-template <typename SP, int NRB>
-__global__ __launch_bounds__(TM_THREADS, 2) void node_update_split_kernel(NodeArgs a) {
-    constexpr int ROWS = 16 * NRB, PLT = SP::NP * ROWS * 256;
-    static_assert(PLT >= ROWS * TM_H * 4, "the fp32 LayerNorm-2 input is aliased on the plane tile pA");
-    __shared__ __attribute__((aligned(16))) char pA[PLT];
-    __shared__ __attribute__((aligned(16))) char pB[PLT];
-    __shared__ __attribute__((aligned(16))) float tB[ROWS * TM_H];
-    float *tA = reinterpret_cast<float *>(pA);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-    const int c32 = lane & 31;
-    const int n_tiles = (a.T + ROWS - 1) / ROWS;
-
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int r0 = tile * ROWS;
-        for (int idx = tid; idx < ROWS * 32; idx += TM_THREADS) {          // aggregated messages -> planes
-            const int row = idx >> 5, c = idx & 31;
-            const f4 v = r0 + row < a.T ? ld4(a.Ssum + (size_t)(r0 + row) * TM_H + 4 * c) : f4{0.f, 0.f, 0.f, 0.f};
-            store_split<SP, ROWS>(pA, row, c, v);
-        }
-        __syncthreads();
-
-        WFragS<SP> wf[2][4];
-        f4 acc[NRB][2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) load_wfrag_split<SP, 4>(a.W3, TM_H, 32 * wv + 16 * cb, 0, TM_H, wf[cb], lane);
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f4{0.f, 0.f, 0.f, 0.f};
-        mma_tile_split<SP, 4, 2, NRB, ROWS>(pA, wf, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-            const int row = r0 + 16 * rb + m;
-            const bool ok = row < a.T;
-            const float c = ok ? a.cnt[row] : 0.f;
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int n = 32 * wv + 16 * cb + 4 * q;
-                const f4 hv = ok ? ld4(a.h_in + (size_t)row * TM_H + n) : f4{0.f, 0.f, 0.f, 0.f};
-                const f4 dh = (acc[rb][cb] + c * ld4(a.b3 + n)) / 30.0f;
-                st4(tB + chunk_off(16 * rb + m, 8 * wv + 4 * cb + q), hv + dh);
-            }
-        }
-        __syncthreads();
-        {   // LN1: fp32 in place (the FFN residual) + planes (the FFN input)
-            const f4 g4 = ld4(a.n1w + 4 * c32), b4 = ld4(a.n1b + 4 * c32);
-#pragma unroll
-            for (int it = 0; it < 2 * NRB; ++it) {
-                const int row = 4 * NRB * wv + 2 * it + (lane >> 5);
-                float *p = tB + chunk_off(row, c32);
-                const f4 y = layer_norm_row(ld4(p), g4, b4);
-                st4(p, y);
-                store_split<SP, ROWS>(pB, row, c32, y);
-            }
-        }
-        __syncthreads();
-
-        f4 out[NRB][2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const f4 b = ld4(a.bout + 32 * wv + 16 * cb + 4 * q);
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) out[rb][cb] = b;
-        }
-        for (int c = 0; c < 4; ++c) {           // FFN hidden 512 in four 128-wide chunks
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int n0 = 128 * c + 32 * wv + 16 * cb;
-                load_wfrag_split<SP, 4>(a.Win, TM_H, n0, 0, TM_H, wf[cb], lane);
-                const f4 b = ld4(a.bin + n0 + 4 * q);
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = b;
-            }
-            mma_tile_split<SP, 4, 2, NRB, ROWS>(pB, wf, acc, lane);
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-                    store_split<SP, ROWS>(pA, 16 * rb + m, 8 * wv + 4 * cb + q, gelu4(acc[rb][cb]));
-            __syncthreads();
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) load_wfrag_split<SP, 4>(a.Wout, 512, 32 * wv + 16 * cb, 128 * c, TM_H, wf[cb], lane);
-            mma_tile_split<SP, 4, 2, NRB, ROWS>(pA, wf, out, lane);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int off = chunk_off(16 * rb + m, 8 * wv + 4 * cb + q);
-                st4(tA + off, ld4(tB + off) + out[rb][cb]);                  // tA aliases pA: every wavefront is past its last read
-            }
-        __syncthreads();
-        {   // LN2, mask, coalesced store; the new state goes into the planes pB for the projections
-            const f4 g4 = ld4(a.n2w + 4 * c32), b4 = ld4(a.n2b + 4 * c32);
-#pragma unroll
-            for (int it = 0; it < 2 * NRB; ++it) {
-                const int row = 4 * NRB * wv + 2 * it + (lane >> 5);
-                const int grow = r0 + row;
-                f4 y = layer_norm_row(ld4(tA + chunk_off(row, c32)), g4, b4);
-                y = grow < a.T ? y * a.mask[grow] : f4{0.f, 0.f, 0.f, 0.f};
-                store_split<SP, ROWS>(pB, row, c32, y);
-                if (grow < a.T) st4(a.h_out + (size_t)grow * TM_H + 4 * c32, y);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const ProjSpec &ps = a.proj[k];
-            if (ps.P == nullptr) continue;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    const int n0 = 32 * wv + 16 * cb;
-                    if (half) load_wfrag_split<SP, 4>(ps.Wc, ps.ldc, n0, 0, TM_H, wf[cb], lane);
-                    else load_wfrag_split<SP, 4>(ps.Wa, ps.lda, n0, 0, TM_H, wf[cb], lane);
-                    const f4 b = half ? f4{0.f, 0.f, 0.f, 0.f} : ld4(ps.ba + n0 + 4 * q);
-#pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = b;
-                }
-                mma_tile_split<SP, 4, 2, NRB, ROWS>(pB, wf, acc, lane);
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) {
-                    const int row = r0 + 16 * rb + m;
-                    if (row < a.T) {
-                        const float *add = half && ps.add_tab ? ps.add_tab + ps.add_idx[row] * TM_H : nullptr;
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) {
-                            const int n = 32 * wv + 16 * cb + 4 * q;
-                            st4(ps.P + (size_t)row * 256 + 128 * half + n, add ? ld4(add + n) + acc[rb][cb] : acc[rb][cb]);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1253,36 +932,10 @@ int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st) {
 }
 
 int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
-    // tile height for load balance, as in launch_node_update; the weight stream is worth more rows of (cheaper) matrix time
-    static const int wcost = [] { const char *e = getenv("TMPNN_NODE_WCOST"); return e ? atoi(e) : 48; }();
-    static const int waves = [] { const char *e = getenv("TMPNN_NODE_WAVES"); return e ? atoi(e) : 8; }();
-    if (waves == 8) {                            // 8-wavefront form: one workgroup per CU, 16..64 rows per tile
-        const int64_t slots = tm_num_cus();
-        static const int max_rows8 = [] { const char *e = getenv("TMPNN_NODE_ROWS"); return e ? atoi(e) : 64; }();
-        int best_rows = max_rows8;
-        int64_t best_cost = -1;
-        for (int rows = max_rows8; rows >= 16; rows -= 16) {
-            const int64_t tiles = (T + rows - 1) / rows, rounds = (tiles + slots - 1) / slots;
-            const int64_t cost = rounds * (rows + wcost);
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rows = rows; }
-        }
-        const int64_t tiles = (T + best_rows - 1) / best_rows;
-        const int grid = (int)(tiles < slots ? tiles : slots);
-#define TM_NODE8(NRB)                                                                    \
-    if (a.img[0]) node_update8_split_kernel<SplitH2, NRB, true><<<grid, 512, 0, st>>>(a); \
-    else node_update8_split_kernel<SplitH2, NRB, false><<<grid, 512, 0, st>>>(a)
-        switch (best_rows) {
-            case 16: TM_NODE8(1); break;
-            case 32: TM_NODE8(2); break;
-            case 48: TM_NODE8(3); break;
-            default: TM_NODE8(4); break;
-        }
-#undef TM_NODE8
-        return tm_check_launch("node_update8_split");
-    }
-    const int64_t slots = (int64_t)2 * tm_num_cus();
-    // (48-row tiles spill 48 VGPRs in this form and still win where they save rounds: 1024 ragged proteins 0.99 vs 1.17 ms)
-    static const int max_rows = [] { const char *e = getenv("TMPNN_NODE_ROWS"); return e ? atoi(e) : 48; }();
+    // tile height (16..64 rows, one workgroup per CU) for load balance: every tile streams the same 0.8 MB of weights,
+    // worth about `wcost` rows of (cheaper) matrix time
+    const int64_t slots = tm_num_cus();
+    const int wcost = 48, max_rows = 64;
     int best_rows = max_rows;
     int64_t best_cost = -1;
     for (int rows = max_rows; rows >= 16; rows -= 16) {
@@ -1292,8 +945,15 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
     }
     const int64_t tiles = (T + best_rows - 1) / best_rows;
     const int grid = (int)(tiles < slots ? tiles : slots);
-    if (best_rows == 16) node_update_split_kernel<SplitH2, 1><<<grid, TM_THREADS, 0, st>>>(a);
-    else if (best_rows == 32) node_update_split_kernel<SplitH2, 2><<<grid, TM_THREADS, 0, st>>>(a);
-    else node_update_split_kernel<SplitH2, 3><<<grid, TM_THREADS, 0, st>>>(a);
-    return tm_check_launch("node_update_split");
+#define TM_NODE8(NRB)                                                                    \
+    if (a.img[0]) node_update8_split_kernel<SplitH2, NRB, true><<<grid, 512, 0, st>>>(a); \
+    else node_update8_split_kernel<SplitH2, NRB, false><<<grid, 512, 0, st>>>(a)
+    switch (best_rows) {
+        case 16: TM_NODE8(1); break;
+        case 32: TM_NODE8(2); break;
+        case 48: TM_NODE8(3); break;
+        default: TM_NODE8(4); break;
+    }
+#undef TM_NODE8
+    return tm_check_launch("node_update8_split");
 }
