@@ -21,6 +21,7 @@ struct HeadArgs {
     float *ddg, *z_opt;
     int T;
     int32_t *status;                      // may be null: TMPNN_STATUS_RANGE is OR-ed in when a ddG is not finite
+    const char *img[12];                  // f16 fragment images of the 12 GEMM units (WImg, tmpnn_internal.h) or all null
 };
 
 __device__ __forceinline__ f4 relu4(f4 v) { return f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
 // fetched from L2 under the MFMAs of unit u (as in node_update8_split_kernel); the two tiny layers (64 -> 32 -> 21) and
 // the ddG epilogue are the fp32 code of head_kernel.
 // ------------------------------------------------------------------------------------------------
-template <typename SP, int NRB>
+template <typename SP, int NRB, bool IMG>
 __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
     constexpr int ROWS = 16 * NRB, PLT = SP::NP * ROWS * 256;
     static_assert(PLT >= ROWS * TM_H * 4, "fp32 tiles of the small layers are aliased on dead x planes");
@@ -162,6 +163,15 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
     };
     f4 raw[8];
     auto issue = [&](int u) {
+        if constexpr (IMG) {                                     // ready-made planes, 8 coalesced loads (see node_update8_split_kernel)
+            const char *p = a.img[u] + (size_t)wv * 8192 + lane * 16;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                raw[2 * c] = *reinterpret_cast<const f4 *>(p + 2048 * c);
+                raw[2 * c + 1] = *reinterpret_cast<const f4 *>(p + 2048 * c + 1024);
+            }
+            return;
+        }
         const float *p = src(u);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -171,6 +181,15 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
     };
     WFragS<SP> wf[1][4];
     auto split_raw = [&]() {
+        if constexpr (IMG) {
+            static_assert(SP::NP == 2, "the fragment images hold the two f16x2 planes");
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                wf[0][c].p[0] = __builtin_bit_cast(u4, raw[2 * c]);
+                wf[0][c].p[1] = __builtin_bit_cast(u4, raw[2 * c + 1]);
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             unsigned w4[4][SP::NP];
@@ -364,7 +383,13 @@ int launch_prep_tables(tmpnn_weights *w, hipStream_t st) {
 int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg,
                 float *z_opt, int32_t *status, hipStream_t st) {
     HeadArgs a{w->conv_center, w->conv_b, w->mlp_w[0], w->mlp_b[0], w->mlp_w[1], w->mlp_b[1], w->mlp_w[2], w->mlp_b[2],
-               w->ddg_w, w->ddg_b, w->Ws_w, hA, hB, S, ddg, z_opt, (int)T, status};
+               w->ddg_w, w->ddg_b, w->Ws_w, hA, hB, S, ddg, z_opt, (int)T, status, {}};
+    bool have_img = tm_matmul_mode() == TM_MM_F16X2;
+    for (int u = 0; u < 12 && have_img; ++u) {
+        a.img[u] = tm_find_wimg(u < 9 ? w->conv_center + (size_t)128 * (u / 3) * 384 + 128 * (u % 3) : w->mlp_w[0] + 128 * (u - 9));
+        have_img = a.img[u] != nullptr;
+    }
+    if (!have_img) for (int u = 0; u < 12; ++u) a.img[u] = nullptr;
     // tile height for load balance, as in node_update: 1 workgroup per CU, ~1.2 MB of weights streamed per tile
     const int64_t slots = tm_num_cus();
     int best_rows = 48;
@@ -379,9 +404,13 @@ int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const 
     tm_prof_begin("head", st);
     static const bool split_ok = [] { const char *e = getenv("TMPNN_HEAD_SPLIT"); return e == nullptr || e[0] != '0'; }();
     if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
-        if (best_rows == 16) head8_split_kernel<SplitH2, 1><<<grid, 512, 0, st>>>(a);
-        else if (best_rows == 32) head8_split_kernel<SplitH2, 2><<<grid, 512, 0, st>>>(a);
-        else head8_split_kernel<SplitH2, 3><<<grid, 512, 0, st>>>(a);
+#define TM_HEAD8(NRB)                                                             \
+    if (a.img[0]) head8_split_kernel<SplitH2, NRB, true><<<grid, 512, 0, st>>>(a); \
+    else head8_split_kernel<SplitH2, NRB, false><<<grid, 512, 0, st>>>(a)
+        if (best_rows == 16) { TM_HEAD8(1); }
+        else if (best_rows == 32) { TM_HEAD8(2); }
+        else { TM_HEAD8(3); }
+#undef TM_HEAD8
         tm_prof_end(st);
         return tm_check_launch("ddg_head");
     }
