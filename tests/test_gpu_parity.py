@@ -434,6 +434,12 @@ def test_centrality_and_baseline_and_scan(tmp_path, engine, synthetic_weights):
     ca0 = torch.tensor(full["coords_chain_A"]["CA_chain_A"])
     assert int(r["neighbors"]) == int(((torch.cdist(ca0, ca0) < 10.0).sum(-1) - 1)[17])
     assert int(rows[194 + 17]["neighbors"]) == int(want[17])     # second file = the gapped structure
+    # every residue of the gapped / missing-atom structure: the scan masks centrality on the CA atom only, like the reference
+    # (a residue that lacks N / C / O but has its CA still counts and is counted)
+    seq_gap = pdb[0]["seq"]
+    pos_rows = {int(r_["position"]): int(r_["neighbors"]) for r_ in rows[194:]}
+    assert sorted(pos_rows) == [k for k, c in enumerate(seq_gap) if c != "-"]
+    assert all(pos_rows[k] == int(want[k]) for k in pos_rows)
 
 
 def _random_protein(rng, L, n_chains=1, p_missing=0.0):
