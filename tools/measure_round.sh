@@ -4,13 +4,14 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r02}; O=$R/gpurun_out
 mkdir -p $O
 cd $R
+bash tools/pmc_traffic.sh > $O/${TAG}_pmc_traffic.log 2>&1
+cp $O/pmc_traffic/pmc_traffic.json $O/${TAG}_pmc_traffic.json; cp $O/pmc_traffic/FETCH_SIZE_per_kernel.csv $O/${TAG}_pmc_FETCH_SIZE_per_kernel.csv; cp $O/pmc_traffic/WRITE_SIZE_per_kernel.csv $O/${TAG}_pmc_WRITE_SIZE_per_kernel.csv
+cp $O/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json   # bench.py reads the stamped file: PMC pass first, so the bench line of THIS call carries traffic
 python bench.py > $O/${TAG}_bench_full.json 2> $O/${TAG}_bench_full.err
 python tools/run_configs.py > $O/${TAG}_configs_2to5.json 2> $O/${TAG}_configs.err
 ( cd /tmp && export TMPDIR=/tmp && rm -rf $O/prof_$TAG && \
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 10 --warmup 3 --no-extras > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err )
 cp $(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv 2>/dev/null
-bash tools/pmc_traffic.sh > $O/${TAG}_pmc_traffic.log 2>&1
-cp $O/pmc_traffic/pmc_traffic.json $O/${TAG}_pmc_traffic.json; cp $O/pmc_traffic/FETCH_SIZE_per_kernel.csv $O/${TAG}_pmc_FETCH_SIZE_per_kernel.csv; cp $O/pmc_traffic/WRITE_SIZE_per_kernel.csv $O/${TAG}_pmc_WRITE_SIZE_per_kernel.csv
 bash tools/pmc_sq.sh > $O/${TAG}_pmc_sq.log 2>&1
 cp $O/pmc_sq_summary.txt $O/${TAG}_pmc_sq_summary.txt
 rm -rf $O/prof_$TAG/*/*.db 2>/dev/null
