@@ -250,6 +250,9 @@ def main():
                     help="timed workload only (no gather microbench / single-protein leg / cpu baseline): use under rocprofv3")
     args = ap.parse_args()
 
+    if os.environ.get("TMPNN_BENCH_WATCHDOG"):     # debugging aid: dump every thread's stack and exit if the run takes longer than N s
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["TMPNN_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -284,7 +287,7 @@ def main():
     pending = [None, None]
     step_no = [0]
 
-    def step():
+    def step(gather=True):
         k = step_no[0] & 1 if world > 1 else 0
         if world > 1 and pending[k] is not None:
             pending[k].wait()
@@ -292,7 +295,9 @@ def main():
         # check_status=False: nothing in the step synchronises; the device status word is read once after the timed region
         eng.ssm_forward(batch["X"], batch["S"], batch["mask"], batch["ridx"], batch["cenc"], batch["offsets"],
                         max_len=L, out=outs[k], check_status=False)
-        if world > 1 and backend == "nccl":
+        if world > 1 and not gather:
+            pass
+        elif world > 1 and backend == "nccl":
             pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k]["ddg"], async_op=True)
         elif world > 1:                                  # gloo smoke mode (all ranks on one GPU): staged through the host
             host = outs[k]["ddg"].cpu()
@@ -313,10 +318,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # fixed clock warm-up (not counted in --warmup): the shader clock settles over the first ~0.3 s of sustained load
+    # fixed clock warm-up (not counted in --warmup): the shader clock settles over the first ~0.3 s of sustained load.
+    # Forward only, NO collective: the loop is bounded by each rank's own clock, so ranks run different numbers of
+    # iterations — a collective in here deadlocks intermittently (caught by tests/test_gpu_parity.py::test_two_rank_bench_and_cli).
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < 0.3:
-        step()
+        step(gather=False)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()

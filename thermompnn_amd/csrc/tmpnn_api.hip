@@ -377,12 +377,11 @@ static NodeProj dec_msg_proj(const tmpnn_weights *w, int l, float *P, const int3
 
 // have_P: ws.P already holds this layer's message projection (written by the previous node_update)
 static int run_enc_layer(const tmpnn_weights *w, int l, float *hV, float *hE, const int32_t *E_idx, const float *mask,
-                         int64_t T, const LayerWs &ws, bool have_P, const NodeProj *next, hipStream_t st, bool hV_is_zero = false) {
+                         int64_t T, const LayerWs &ws, bool have_P, const NodeProj *next, hipStream_t st) {
     const EncW &e = w->enc[l];
     if (!have_P) {
         const NodeProj mp = enc_msg_proj(w, l, ws.P);
-        if (hV_is_zero) TRY(launch_node_proj_zero(mp, T, st));
-        else TRY(launch_node_proj(hV, mp, T, st));
+        TRY(launch_node_proj(hV, mp, T, st));
     }
     // message + node update (EncLayer :819-832); the update also projects the NEW state for the edge update
     TRY(launch_msg(false, e.W1 + 128, 384, e.W2, e.b2, ws.P, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
@@ -554,15 +553,14 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     if (E_idx_opt) E_idx = E_idx_opt;
     if (hidden_opt) for (int l = 0; l < 3; ++l) hV[1 + l] = hidden_opt + (size_t)l * T * TMPNN_HID;
 
-    TRY(launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, status_opt, st));
+    // h_V starts at zero (:1228): the k-NN kernel writes that state and its message projection [b1 | 0] as it goes, and
+    // node_update of every layer writes the projection the next message pass needs into ws.P — 18 launches per forward
+    // (28 when every projection and the zero state are launches of their own)
+    TRY(launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, status_opt, st, KnnInit{hV[0], ws.P, w->enc[0].b1}));
     TRY(launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, hE, nullptr, st));
-    if (hipMemsetAsync(hV[0], 0, (size_t)T * TMPNN_HID * 4, st) != hipSuccess)          // h_V starts at zero (:1228)
-        return tm_set_error(TMPNN_E_LAUNCH, "ssm_forward: memset failed");
-    // node_update of every layer also writes the projection the next message pass needs into ws.P, so only the
-    // very first projection (of the all-zero state) is a separate launch: 20 launches per forward instead of 28
     for (int l = 0; l < 3; ++l) {
         const NodeProj next = l < 2 ? enc_msg_proj(w, l + 1, ws.P) : dec_msg_proj(w, 0, ws.P, S);
-        TRY(run_enc_layer(w, l, hV[0], hE, E_idx, mask, T, ws, l > 0, &next, st, l == 0));
+        TRY(run_enc_layer(w, l, hV[0], hE, E_idx, mask, T, ws, true, &next, st));
     }
     for (int l = 0; l < 3; ++l) {
         const NodeProj next = dec_msg_proj(w, l < 2 ? l + 1 : 2, ws.P, S);

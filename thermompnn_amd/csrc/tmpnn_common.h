@@ -48,6 +48,19 @@ __device__ __forceinline__ TileRange xcd_tile_range(int n_tiles) {
 template <int RS = 128>
 __device__ __forceinline__ int chunk_off(int m, int c) { return m * RS + ((c ^ (m & 15)) << 2); }
 
+// Kernel arguments live in device memory; hipcc fetches them in several dependent groups (SGPR pressure, control flow), each
+// a ~0.6 us round trip on a cold argument buffer. One dword of every 64-byte line, requested back to back at kernel entry,
+// pulls the whole argument block into the scalar cache in ONE round trip; the compiler's own s_loads then hit.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+    typedef const __attribute__((address_space(4))) unsigned *kptr;
+    kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned any = 0;
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) any |= k[o / 4];
+    asm volatile("" ::"s"(any));
+}
+
 __device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
 
@@ -272,10 +285,19 @@ __device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 l
 
 // LayerNorm of one 128-wide row held as one f4 per lane of a half-wavefront (nn.LayerNorm, eps 1e-5,
 // biased variance). g4/b4 = this lane's 4 gamma/beta values.
+// s a + c per component as explicit fmas (see layer_norm_row for why)
+__device__ __forceinline__ f4 fma4s(float s, f4 a, f4 c) {
+    return f4{__builtin_fmaf(s, a.x, c.x), __builtin_fmaf(s, a.y, c.y), __builtin_fmaf(s, a.z, c.z), __builtin_fmaf(s, a.w, c.w)};
+}
+// The sum of squares and the affine step are written as explicit fma chains: with -ffp-contract=fast hipcc otherwise picks a
+// different mul / fma mix for the same source in different kernels (measured: one ulp between two node_update forms), and
+// results must not depend on which form of a kernel a batch size selects.
 __device__ __forceinline__ f4 layer_norm_row(f4 v, f4 g4, f4 b4) {
     const float mean = half_wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 128.0f);
     const f4 d = v - mean;
-    const float var = half_wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / 128.0f);
+    const float ss = __builtin_fmaf(d.w, d.w, __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x)));
+    const float var = half_wave_sum(ss) * (1.0f / 128.0f);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    return d * rstd * g4 + b4;
+    const f4 t = d * rstd;
+    return f4{__builtin_fmaf(t.x, g4.x, b4.x), __builtin_fmaf(t.y, g4.y, b4.y), __builtin_fmaf(t.z, g4.z, b4.z), __builtin_fmaf(t.w, g4.w, b4.w)};
 }

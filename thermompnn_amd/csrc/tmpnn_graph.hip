@@ -136,12 +136,17 @@ __device__ __forceinline__ void knn_row(float *d, const float *__restrict__ X, c
 __global__ __launch_bounds__(TM_THREADS, 8) void knn_kernel(const float *__restrict__ X, const float *__restrict__ mask,
                                                             const int32_t *__restrict__ offsets, int N, int T, int max_len,
                                                             int K, int32_t *__restrict__ E_idx, float *__restrict__ D_nb,
-                                                            int32_t *__restrict__ status) {
+                                                            int32_t *__restrict__ status, KnnInit init) {
     extern __shared__ __attribute__((aligned(16))) float knn_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float *d = knn_lds + (size_t)wv * (max_len + (max_len >> 6) + 1);
 
     for (int i = blockIdx.x * 4 + wv; i < T; i += gridDim.x * 4) {
+        if (init.hV0) {      // the fused forward: this residue's all-zero initial state and its projection (W . 0 + b = b exactly)
+            const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+            if (lane < 32) st4(init.hV0 + (size_t)i * TM_H + 4 * lane, z);
+            st4(init.P + (size_t)i * 256 + 4 * lane, lane < 32 ? ld4(init.ba + 4 * lane) : z);
+        }
         int lo = 0, hi = N;                      // protein p with offsets[p] <= i < offsets[p+1]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -603,7 +608,7 @@ int launch_centrality(const float *X, const float *mask, const int32_t *offsets,
 }
 
 int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,
-               int32_t *E_idx, float *D_nb, int32_t *status, hipStream_t st) {
+               int32_t *E_idx, float *D_nb, int32_t *status, hipStream_t st, KnnInit init) {
     const size_t lds = (size_t)4 * (max_len + (max_len >> 6) + 1) * sizeof(float);   // knn_slot padding
     if (lds > 160 * 1024) return tm_set_error(TMPNN_E_UNSUPPORTED, "knn_topk: max_len %d needs %zu B of LDS", max_len, lds);
     // per call, not cached: the attribute is per device and one process may drive several GPUs
@@ -611,7 +616,7 @@ int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N,
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int64_t blocks = (T + 3) / 4;
     const int64_t cap = (int64_t)tm_num_cus() * 8;
-    { tm_prof_begin("knn", st); knn_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status); tm_prof_end(st); }
+    { tm_prof_begin("knn", st); knn_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init); tm_prof_end(st); }
     return tm_check_launch("knn_topk");
 }
 

@@ -55,8 +55,12 @@ void tm_prof_begin(const char *name, hipStream_t st);   // no-ops unless tmpnn_p
 void tm_prof_end(hipStream_t st);
 
 // tmpnn_graph.hip
+// Optional extra of the fused forward: the k-NN kernel (one wavefront per residue) also writes the residue's all-zero initial
+// node state hV0[t, 0:128] and its message projection P[t] = [ba | 0] (what node_proj of a zero state gives, exactly) —
+// two launches (a memset and a fill) fewer per forward.
+struct KnnInit { float *hV0; float *P; const float *ba; };
 int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,
-               int32_t *E_idx, float *D_nb, int32_t *status, hipStream_t st);
+               int32_t *E_idx, float *D_nb, int32_t *status, hipStream_t st, KnnInit init = KnnInit{nullptr, nullptr, nullptr});
 int launch_centrality(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, float radius,
                       int32_t *out, hipStream_t st);
 int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx, const int32_t *cenc,
@@ -83,7 +87,6 @@ struct NodeArgs {
 };
 int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st);
 int launch_node_proj(const float *h, const NodeProj &np, int64_t T, hipStream_t st);
-int launch_node_proj_zero(const NodeProj &np, int64_t T, hipStream_t st);       // the same for h == 0 (a fill)
 int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
                        const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,

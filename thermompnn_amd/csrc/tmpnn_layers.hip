@@ -484,22 +484,6 @@ static int grid_for(int64_t work_items, int blocks_per_cu) {
     return (int)(work_items < cap ? (work_items < 1 ? 1 : work_items) : cap);
 }
 
-// Projection of the ALL-ZERO initial node state (ProteinMPNN.forward starts h_V at zeros, protein_mpnn_utils.py:1228):
-// W . 0 + b = b exactly, so P[t, 0:128] = ba and P[t, 128:256] = 0 — a fill instead of a GEMM launch (bit-identical).
-__global__ void node_proj_zero_kernel(const float *__restrict__ ba, float *__restrict__ P, int64_t n4) {
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(k & 63);                    // 16-byte chunk within the 256-float row
-        st4(P + 4 * k, c < 32 ? ld4(ba + 4 * c) : f4{0.f, 0.f, 0.f, 0.f});
-    }
-}
-int launch_node_proj_zero(const NodeProj &np, int64_t T, hipStream_t st) {
-    const int64_t n4 = T * 64, blocks = (n4 + 255) / 256, cap = (int64_t)tm_num_cus() * 8;
-    tm_prof_begin("node_proj", st);
-    node_proj_zero_kernel<<<(int)(blocks < cap ? blocks : cap), 256, 0, st>>>(np.ba, np.P, n4);
-    tm_prof_end(st);
-    return tm_check_launch("node_proj_zero");
-}
-
 int launch_node_proj(const float *h, const NodeProj &np, int64_t T, hipStream_t st) {
     const int64_t tiles = (T + TM_TILE - 1) / TM_TILE;
     { tm_prof_begin("node_proj", st); node_proj_kernel<<<grid_for(tiles, 2), TM_THREADS, 0, st>>>(h, np.Wa, np.lda, np.ba, np.Wc, np.ldc, (int)T, np.P, np.add_tab, np.add_idx); tm_prof_end(st); }

@@ -12,6 +12,12 @@
 #ifndef TM_NODE_PF
 #define TM_NODE_PF 3
 #endif
+#ifndef TM_NODE_DEEP_D
+#define TM_NODE_DEEP_D 3   // fragment images in flight ahead of the GEMM unit being computed (node_update8_deep_kernel)
+#endif
+#ifndef TM_NODE_DEEP_PF
+#define TM_NODE_DEEP_PF 2  // its B-fragment prefetch distance (a 16-row GEMM has 4 steps; 3 would hold all four at once: 8 more VGPRs)
+#endif
 #ifndef TM_MSG_TOUCH
 #define TM_MSG_TOUCH 1
 #endif
@@ -818,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
                 const bool ok = row < a.T;
                 const float c = ok ? a.cnt[row] : 0.f;
                 const f4 hv = ok ? ld4(a.h_in + (size_t)row * TM_H + ncol) : f4{0.f, 0.f, 0.f, 0.f};
-                const f4 dh = (acc[rb][0] + c * b3) / 30.0f;
+                const f4 dh = fma4s(c, b3, acc[rb][0]) / 30.0f;
                 st4(tB + chunk_off(16 * rb + m, c4), hv + dh);
             }
         }
@@ -912,6 +918,170 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// node_update for FEW residues (every workgroup has exactly one 16-row tile: T <= 16 x #CUs — a single protein or a small
+// batch, the latency case). A tile is a chain of 9..13 dependent GEMM units whose weights come from L2; with one unit
+// requested ahead (the form above) every unit waits out most of an L2 round trip (~0.6 us x 13). Here the fragment images of
+// the next D units are in flight at any time, in a ring of D + 1 register slots that the MFMAs read in place (a 16-row tile
+// needs few other VGPRs), and every small operand (biases, LayerNorm parameters, the tile's own rows) is requested BEFORE the
+// ring is primed: gfx9's vmcnt retires in order, a later wait for a small load would drain the whole ring.
+// Arithmetic and its order are those of node_update8_split_kernel (bit-identical results).
+// ------------------------------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int NPROJ, int D, bool PROF = false>
+__global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsigned long long *prof = nullptr) {
+    using SP = SplitH2;
+    int n_mark = 0;
+    auto mark = [&]() {                 // TMPNN_NODE_PROF=1: cycle stamps of thread 0 of workgroup 0 at every stage boundary
+        if (PROF && blockIdx.x == 0 && threadIdx.x == 0) prof[n_mark++] = __builtin_readcyclecounter();
+    };
+    mark();
+    kernarg_warm<sizeof(NodeArgs)>();
+    constexpr int ROWS = 16, PLT = SP::NP * ROWS * 256, NPOS = 9 + 2 * NPROJ, NS = D + 1;
+    static_assert(PLT >= ROWS * TM_H * 4, "the fp32 LayerNorm-2 input is aliased on the plane tile pA");
+    __shared__ __attribute__((aligned(16))) char pA[PLT];
+    __shared__ __attribute__((aligned(16))) char pB[PLT];
+    __shared__ __attribute__((aligned(16))) float tB[ROWS * TM_H];
+    float *tA = reinterpret_cast<float *>(pA);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int c32 = lane & 31, hw = tid >> 5;                  // half-wavefront hw owns row hw in the row phases
+    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
+    const int r0 = blockIdx.x * ROWS;                           // the launcher starts exactly ceil(T / 16) workgroups
+    // The launcher compacts the projections (the NPROJ present ones first, their images in img[9..]): every kernel argument
+    // is then read at a fixed offset and the scalar loads form one cluster (a dependent second round trip to the freshly
+    // written argument buffer costs ~0.5 us).
+    constexpr int pk[2] = {0, 1};
+    // unit of position p: 0 = W3; 1 + 2c / 2 + 2c = W_in / W_out chunk c; then the A and C halves of the projections
+    auto unit_at = [&](int p) { return p; };
+
+    // ---- small operands first. Every load is unconditional (rows past T are clamped to the tile's first row and masked
+    // afterwards, absent tables are replaced by a valid dummy) so that hipcc keeps the scalar argument loads in one cluster and
+    // the vector loads back to back: conditional loads became a chain of s_load / s_waitcnt / branch blocks (2 us of the tile).
+    const f4 z4 = f4{0.f, 0.f, 0.f, 0.f};
+    const int row_m = r0 + m, grow = r0 + hw;
+    const bool ok_m = row_m < a.T, ok_h = grow < a.T;
+    const int row_c = ok_m ? row_m : r0, grow_c = ok_h ? grow : r0;
+    const f4 sv_raw = ld4(a.Ssum + (size_t)grow_c * TM_H + 4 * c32);             // ROWS * 32 chunks = one per thread
+    const f4 hv_raw = ld4(a.h_in + (size_t)row_c * TM_H + ncol);
+    const float cnt_raw = a.cnt[row_c], mk_raw = a.mask[grow_c];
+    bool has_add[2] = {false, false};
+    int add_row[2] = {0, 0};
+    f4 pb[2] = {z4, z4}, padd[2] = {z4, z4};
+#pragma unroll
+    for (int k = 0; k < NPROJ; ++k) {
+        const ProjSpec &ps = a.proj[pk[k]];
+        has_add[k] = ps.add_tab != nullptr;
+        add_row[k] = (has_add[k] ? ps.add_idx : reinterpret_cast<const int32_t *>(a.cnt))[row_c];
+        pb[k] = ld4(ps.ba + ncol);
+    }
+    const f4 b3 = ld4(a.b3 + ncol), bout = ld4(a.bout + ncol);
+    f4 bin[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bin[c] = ld4(a.bin + 128 * c + ncol);
+    const f4 g1 = ld4(a.n1w + 4 * c32), be1 = ld4(a.n1b + 4 * c32), g2 = ld4(a.n2w + 4 * c32), be2 = ld4(a.n2b + 4 * c32);
+
+    // ---- the ring
+    WFragS<SP> ring[NS][1][4];
+    auto issue = [&](auto P) {
+        constexpr int p = decltype(P)::value;
+        if constexpr (p < NPOS) {
+            const char *src = a.img[unit_at(p)] + (size_t)wv * 8192 + lane * 16;
+            __builtin_amdgcn_sched_barrier(0);                  // the loads stay HERE: hoisted, they would need more slots
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                ring[p % NS][0][c].p[0] = *reinterpret_cast<const u4 *>(src + 2048 * c);
+                ring[p % NS][0][c].p[1] = *reinterpret_cast<const u4 *>(src + 2048 * c + 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    static_for<0, D>(issue);
+    // (the masks use the loaded values: in front of the ring they would make it wait for them)
+    const f4 sv = ok_h ? sv_raw : z4, hv = ok_m ? hv_raw : z4;
+    const float cnt = ok_m ? cnt_raw : 0.f, mk = ok_h ? mk_raw : 0.f;
+    // the one dependent gather (index -> table row) goes AFTER the ring: its index is older than the ring's loads, so waiting
+    // for it drains nothing, and its rows are not needed before the last GEMM unit
+#pragma unroll
+    for (int k = 0; k < NPROJ; ++k) {
+        asm volatile("" : "+v"(add_row[k]));                    // first use of the index HERE (its vmcnt wait comes with it)
+        const f4 t = ld4((has_add[k] ? a.proj[pk[k]].add_tab + (size_t)add_row[k] * TM_H : a.b3) + ncol);
+        padd[k] = has_add[k] && ok_m ? t : z4;
+    }
+    mark();
+
+    store_split<SP, ROWS>(pA, hw, c32, sv);                     // aggregated messages -> planes
+    __syncthreads();
+    mark();
+
+    f4 acc[1][1];
+    issue(std::integral_constant<int, D>{});
+    acc[0][0] = z4;
+    mma_tile_split<SP, 4, 1, 1, ROWS, 256, 4, 0, true, TM_NODE_DEEP_PF>(pA, ring[0], acc, lane);             // W3
+    {
+        const f4 dh = fma4s(cnt, b3, acc[0][0]) / 30.0f;
+        st4(tB + chunk_off(m, c4), hv + dh);
+    }
+    __syncthreads();
+    mark();
+    {   // LN1: fp32 in place (the FFN residual) + planes (the FFN input)
+        float *p = tB + chunk_off(hw, c32);
+        const f4 y = layer_norm_row(ld4(p), g1, be1);
+        st4(p, y);
+        store_split<SP, ROWS>(pB, hw, c32, y);
+    }
+    __syncthreads();
+    mark();
+
+    f4 out[1][1];
+    out[0][0] = bout;
+    static_for<0, 4>([&](auto C) {                              // FFN hidden 512 in four 128-wide chunks
+        constexpr int c = decltype(C)::value;
+        issue(std::integral_constant<int, 1 + 2 * c + D>{});
+        acc[0][0] = bin[c];
+        mma_tile_split<SP, 4, 1, 1, ROWS, 256, 4, 0, true, TM_NODE_DEEP_PF>(pB, ring[(1 + 2 * c) % NS], acc, lane);
+        store_split<SP, ROWS>(pA, m, c4, gelu4(acc[0][0]));
+        __syncthreads();
+        mark();
+        issue(std::integral_constant<int, 2 + 2 * c + D>{});
+        mma_tile_split<SP, 4, 1, 1, ROWS, 256, 4, 0, true, TM_NODE_DEEP_PF>(pA, ring[(2 + 2 * c) % NS], out, lane);
+        __syncthreads();
+        mark();
+    });
+    {
+        const int off = chunk_off(m, c4);
+        st4(tA + off, ld4(tB + off) + out[0][0]);               // tA aliases pA: every wavefront is past its last read
+    }
+    __syncthreads();
+    {   // LN2, mask, coalesced store; the new state goes into the planes pB for the projections
+        f4 y = layer_norm_row(ld4(tA + chunk_off(hw, c32)), g2, be2);
+        y = ok_h ? y * mk : z4;
+        store_split<SP, ROWS>(pB, hw, c32, y);
+        if (ok_h) st4(a.h_out + (size_t)grow * TM_H + 4 * c32, y);
+    }
+    mark();
+    if constexpr (NPROJ > 0) {
+        __syncthreads();
+        static_for<0, 2 * NPROJ>([&](auto J) {
+            constexpr int j = decltype(J)::value, k = j >> 1, half = j & 1;
+            issue(std::integral_constant<int, 9 + j + D>{});
+            acc[0][0] = half ? z4 : pb[k];
+            mma_tile_split<SP, 4, 1, 1, ROWS, 256, 4, 0, true, TM_NODE_DEEP_PF>(pB, ring[(9 + j) % NS], acc, lane);
+            if (ok_m) {
+                float *dst = a.proj[pk[k]].P + (size_t)row_m * 256 + 128 * half + ncol;
+                st4(dst, half && has_add[k] ? padd[k] + acc[0][0] : acc[0][0]);
+            }
+            mark();
+        });
+    }
+}
+
 // fragment image of one 128 x 128 block (see WImg in tmpnn_internal.h): [wv 8][c 4][plane 2][lane 64] x 16 B
 __global__ void prep_wimg_kernel(const float *__restrict__ W, int ld, int n_rows, char *__restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (wv, c, lane)
@@ -949,6 +1119,38 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
     }
     const int64_t tiles = (T + best_rows - 1) / best_rows;
     const int grid = (int)(tiles < slots ? tiles : slots);
+    static const int deep = [] { const char *e = getenv("TMPNN_NODE_DEEP"); return e ? atoi(e) : 1; }();
+    if (deep && a.img[0] && (T + 15) / 16 <= slots) {           // one 16-row tile per workgroup: the deep-prefetch form
+        const int g16 = (int)((T + 15) / 16);
+        const int np = (a.proj[0].P != nullptr) + (a.proj[1].P != nullptr);
+        NodeArgs b = a;
+        if (np == 1 && a.proj[0].P == nullptr) {                // compact: the present projection first
+            b.proj[0] = a.proj[1];
+            b.proj[1] = a.proj[0];
+            b.img[9] = a.img[11];
+            b.img[10] = a.img[12];
+        }
+        static const bool prof = [] { const char *e = getenv("TMPNN_NODE_PROF"); return e != nullptr && e[0] == '1'; }();
+        if (prof && np == 2) {                                  // debug: stage stamps of workgroup 0 (synchronises!)
+            static unsigned long long *d_prof = nullptr;
+            if (!d_prof) (void)hipMalloc(&d_prof, 32 * sizeof(unsigned long long));
+            (void)hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), st);
+            node_update8_deep_kernel<2, TM_NODE_DEEP_D, true><<<g16, 512, 0, st>>>(b, d_prof);
+            unsigned long long h[32];
+            (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "node_update8_deep stages (cycles since entry, wg 0): primed %llu | planes %llu | W3 %llu | LN1 %llu |", h[1] - h[0],
+                    h[2] - h[0], h[3] - h[0], h[4] - h[0]);
+            for (int k = 5; k < 13; ++k) fprintf(stderr, " %llu", h[k] - h[0]);
+            fprintf(stderr, " | LN2 %llu | proj", h[13] - h[0]);
+            for (int k = 14; k < 18; ++k) fprintf(stderr, " %llu", h[k] - h[0]);
+            fprintf(stderr, "\n");
+            return tm_check_launch("node_update8_deep");
+        }
+        if (np == 0) node_update8_deep_kernel<0, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
+        else if (np == 1) node_update8_deep_kernel<1, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
+        else node_update8_deep_kernel<2, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
+        return tm_check_launch("node_update8_deep");
+    }
 #define TM_NODE8(NRB)                                                                    \
     if (a.img[0]) node_update8_split_kernel<SplitH2, NRB, true><<<grid, 512, 0, st>>>(a); \
     else node_update8_split_kernel<SplitH2, NRB, false><<<grid, 512, 0, st>>>(a)

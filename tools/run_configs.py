@@ -61,7 +61,7 @@ b = pack([256], [0])
 dt, k = run(b, 200, 10)
 res["engine_precision"] = eng.precision
 res["config2_single_L256"] = {"ms": dt * 1e3, "preds_per_s": 5120 / dt, "kernel_avg_ms": k, "gpu_kernel_ms": sum(
-    v * {"node_proj": 9, "enc_msg": 3, "dec_msg": 3, "enc_edge": 3, "node_update": 6}.get(n, 1) for n, v in k.items())}
+    v * {"enc_msg": 3, "dec_msg": 3, "enc_edge": 3, "node_update": 6}.get(n, 1) for n, v in k.items())}
 # config 3: 1024 ragged proteins, L ~ U[64, 512]
 lens = np.random.default_rng(1).integers(64, 513, size=1024)
 t0 = time.perf_counter(); b = pack(lens, 1000 + np.arange(1024)); gen_s = time.perf_counter() - t0
