@@ -708,7 +708,8 @@ def test_two_rank_bench_and_cli(tmp_path):
     import json
     repo = os.path.dirname(os.path.dirname(GOLDEN))
     r = _torchrun([os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--proteins-per-gpu", "2"],
-                  {"TMPNN_BENCH_ONE_DEVICE": "1", "TMPNN_BENCH_BACKEND": "gloo"})
+                  {"TMPNN_BENCH_ONE_DEVICE": "1", "TMPNN_BENCH_BACKEND": "gloo", "TMPNN_BENCH_WARMUP_SKEW": "1",
+                   "TMPNN_BENCH_WATCHDOG": "120"})     # ranks warm up for different times: no collective may sit in that loop
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["preds_per_step"] == 2 * 2 * 256 * 20
