@@ -28,6 +28,9 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
+#ifndef TM_SPLIT_MIX
+#define TM_SPLIT_MIX 0     // 1: SplitH2::split2 through v_fma_mixlo/hi_f16 (same bits, 3 instead of 5 VALU ops per pair; measured: enc_edge -1 %, dec_msg +2 %, net nil — off)
+#endif
 #define SPLIT_PLANE_BYTES (TM_TILE * TM_H * 2)   // one 48 x 128 plane of 16-bit values: 12288 B
 
 // ------------------------------------------------------------------------------------------------
@@ -76,10 +79,20 @@ struct SplitH2 {
     // second accumulator and no fold after the GEMM (VALU is what bounds these kernels).
     static __device__ __forceinline__ void split2(f2 x, unsigned (&p)[2]) {
         const h2 h = __builtin_convertvector(x, h2);                        // v_cvt_pk_f16_f32, RNE
+        p[0] = __builtin_bit_cast(unsigned, h);
+#if TM_SPLIT_MIX
+        // l = fp16(x - h) per half in ONE mixed-precision fma each (f32 x, f16 h read in place, f16 result written into its
+        // half of the destination): 3 VALU ops per pair instead of 5 (two v_cvt_f32_f16, a packed subtract, a packed
+        // convert). Same bits — tools/probe/mix_split_check.hip compares the two forms on 4 M random pairs.
+        unsigned l;
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x.x), "v"(p[0]));
+        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x.y), "v"(p[0]));
+        p[1] = l;
+#else
         const f2 r = x - __builtin_convertvector(h, f2);                    // exact
         const h2 l = __builtin_convertvector(r, h2);
-        p[0] = __builtin_bit_cast(unsigned, h);
         p[1] = __builtin_bit_cast(unsigned, l);
+#endif
     }
     static __device__ __forceinline__ f2 join2(const unsigned (&p)[2]) {
         const f2 h = __builtin_convertvector(__builtin_bit_cast(h2, p[0]), f2);
