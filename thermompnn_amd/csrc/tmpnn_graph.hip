@@ -133,7 +133,80 @@ __device__ __forceinline__ void knn_row(float *d, const float *__restrict__ X, c
     wave_lds_fence();
 }
 
-__global__ __launch_bounds__(TM_THREADS, 8) void knn_kernel(const float *__restrict__ X, const float *__restrict__ mask,
+// Rows of at most 64 NS residues (NS = 4 or 8): the whole row lives in registers, NS candidates per lane (j = lane + 64 k).
+// Each lane sorts its own stripe once (odd-even transposition with a strict compare: stable, so equal distances keep their
+// index order), after which a selection round is a wavefront min over the lanes' heads and a register shift in the owner
+// lane — no LDS, no divergent rescan. Same arithmetic, same (distance, index) order as knn_row.
+template <int NS>
+__device__ __forceinline__ void knn_row_reg(const float *__restrict__ X, const float *__restrict__ mask, int i, int s, int L,
+                                            int Keff, int lane, int32_t *__restrict__ E_idx, float *__restrict__ D_nb) {
+    const float xi = X[(size_t)i * 12 + 3], yi = X[(size_t)i * 12 + 4], zi = X[(size_t)i * 12 + 5];
+    const float mi = mask[i];
+    float D[NS], m2[NS];
+    float dmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int j = lane + 64 * k, jc = j < L ? j : 0;        // (a valid row for the loads of the empty slots)
+        const float *c = X + (size_t)(s + jc) * 12 + 3;
+        const float dx = c[0] - xi, dy = c[1] - yi, dz = c[2] - zi;
+        const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        m2[k] = mi * mask[s + jc];
+        D[k] = __fmul_rn(m2[k], sqrtf(__fadd_rn(s2, 1e-6f)));
+        if (j < L) dmax = fmaxf(dmax, D[k]);
+    }
+    dmax = wave_max_f32(dmax);
+    unsigned v[NS], id[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const float Da = __fadd_rn(D[k], __fmul_rn(1.0f - m2[k], dmax));
+        v[k] = lane + 64 * k < L ? __float_as_uint(Da) : 0xffffffffu;    // distances are >= +0: their bits order like the values
+        id[k] = (unsigned)k;
+    }
+#pragma unroll
+    for (int r = 0; r < NS; ++r)
+#pragma unroll
+        for (int k = r & 1; k + 1 < NS; k += 2) {
+            const bool sw = v[k] > v[k + 1];
+            const unsigned a = v[k], b = v[k + 1], ia = id[k], ib = id[k + 1];
+            v[k] = sw ? b : a;
+            v[k + 1] = sw ? a : b;
+            id[k] = sw ? ib : ia;
+            id[k + 1] = sw ? ia : ib;
+        }
+    int out_j = -1;                                              // lane t keeps the t-th neighbour: one coalesced store per row
+    float out_d = 0.f;
+    for (int t = 0; t < Keff; ++t) {
+        const unsigned g = wave_min_u32(v[0]);
+        const unsigned long long tied = __ballot(v[0] == g);
+        unsigned j;
+        if (__popcll(tied) == 1) {                               // the common case: one lane holds the minimum
+            const int o = (int)__ffsll((long long)tied) - 1;
+            j = ((unsigned)__builtin_amdgcn_readlane((int)id[0], o) << 6) | (unsigned)o;
+        } else {                                                 // exact tie between lanes: lowest index wins
+            j = wave_min_u32(v[0] == g ? (id[0] << 6) | (unsigned)lane : 0xffffffffu);
+        }
+        if (lane == t) {
+            out_j = s + (int)j;
+            out_d = __uint_as_float(g);
+        }
+        const bool mine = lane == (int)(j & 63u);                // the owner lane drops its head
+#pragma unroll
+        for (int k = 0; k + 1 < NS; ++k) {
+            v[k] = mine ? v[k + 1] : v[k];
+            id[k] = mine ? id[k + 1] : id[k];
+        }
+        v[NS - 1] = mine ? 0xffffffffu : v[NS - 1];
+    }
+    if (lane < TM_KS) {                                          // slots >= Keff keep (-1, 0)
+        E_idx[(size_t)i * TM_KS + lane] = out_j;
+        D_nb[(size_t)i * TM_KS + lane] = out_d;
+    }
+}
+
+// NS = 0: rows of any length through LDS (knn_row); NS = 4 / 8: every row of the batch has at most 256 / 512 residues
+// (max_len says so) and runs in registers (knn_row_reg) — no dynamic LDS at all.
+template <int NS>
+__global__ __launch_bounds__(TM_THREADS, NS == 8 ? 4 : 8) void knn_kernel(const float *__restrict__ X, const float *__restrict__ mask,
                                                             const int32_t *__restrict__ offsets, int N, int T, int max_len,
                                                             int K, int32_t *__restrict__ E_idx, float *__restrict__ D_nb,
                                                             int32_t *__restrict__ status, KnnInit init) {
@@ -159,7 +232,8 @@ __global__ __launch_bounds__(TM_THREADS, 8) void knn_kernel(const float *__restr
             continue;
         }
         const int Keff = K < L ? K : L;
-        if (L > 512) knn_row<true>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
+        if constexpr (NS > 0) knn_row_reg<NS>(X, mask, i, s, L, Keff, lane, E_idx, D_nb);
+        else if (L > 512) knn_row<true>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
         else knn_row<false>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
     }
 }
@@ -611,12 +685,20 @@ int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N,
                int32_t *E_idx, float *D_nb, int32_t *status, hipStream_t st, KnnInit init) {
     const size_t lds = (size_t)4 * (max_len + (max_len >> 6) + 1) * sizeof(float);   // knn_slot padding
     if (lds > 160 * 1024) return tm_set_error(TMPNN_E_UNSUPPORTED, "knn_topk: max_len %d needs %zu B of LDS", max_len, lds);
-    // per call, not cached: the attribute is per device and one process may drive several GPUs
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int64_t blocks = (T + 3) / 4;
     const int64_t cap = (int64_t)tm_num_cus() * 8;
-    { tm_prof_begin("knn", st); knn_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init); tm_prof_end(st); }
+    const int grid = (int)(blocks < cap ? blocks : cap);
+    static const bool reg_rows = [] { const char *e = getenv("TMPNN_KNN_REG"); return !(e && e[0] == '0'); }();
+    tm_prof_begin("knn", st);
+    if (reg_rows && max_len <= 256) knn_kernel<4><<<grid, TM_THREADS, 0, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init);
+    else if (reg_rows && max_len <= 512) knn_kernel<8><<<grid, TM_THREADS, 0, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init);
+    else {
+        // per call, not cached: the attribute is per device and one process may drive several GPUs
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        knn_kernel<0><<<grid, TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init);
+    }
+    tm_prof_end(st);
     return tm_check_launch("knn_topk");
 }
 

@@ -202,6 +202,24 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
         }
     };
 
+    // Small operands of every layer once per workgroup, BEFORE the first weight-fragment request (gfx9 retires loads in order:
+    // requested inside the tile, each of these cost its own L2 round trip in front of the MFMAs that needed it — the two tiny
+    // layers' weights after a barrier, the biases at every accumulator initialisation).
+    f4 cb[3], b1v, b2v, b3v;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) cb[g] = ld4(a.conv_b + 128 * g + ncol);
+    b1v = ld4(a.b1 + (ncol & 63));
+    b2v = ld4(a.b2 + (ncol & 31));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = (ncol & 31) + r;
+        b3v[r] = a.b3[n < TMPNN_VOCAB ? n : 0];
+        if (n >= TMPNN_VOCAB) b3v[r] = 0.f;
+    }
+    float w32[1][16], w8[1][8];
+    load_wfrag<4>(a.w2, 64, 16 * (wv & 1), 0, 32, w32[0], lane);
+    load_wfrag<2>(a.w3, 32, 16 * (wv & 1), 0, TMPNN_VOCAB, w8[0], lane);
+
     int tile = blockIdx.x;
     if (tile < n_tiles) issue(0);
     for (; tile < n_tiles; tile += gridDim.x) {
@@ -210,12 +228,16 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
         for (int idx = tid; idx < ROWS * 32; idx += 512) {      // x = [h_last | h_prev | W_s[S]] -> planes
             const int row = idx >> 5, c = idx & 31;
             const bool ok = row < rows;
+            const size_t grow = (size_t)(r0 + (ok ? row : 0));   // rows past T: a valid row, masked below (no branch around the loads)
             // the ReLUs of both_out map NaN to 0, so a poisoned decoder state would come out as a finite ddG: flag it here, on
             // the raw bits as loaded (see tm_nonfinite_bits)
             typedef unsigned uv4 __attribute__((ext_vector_type(4)));
             const uv4 zero4 = uv4{0u, 0u, 0u, 0u};
-            const uv4 ra = ok ? *reinterpret_cast<const uv4 *>(a.hA + (size_t)(r0 + row) * TM_H + 4 * c) : zero4;
-            const uv4 rb = ok ? *reinterpret_cast<const uv4 *>(a.hB + (size_t)(r0 + row) * TM_H + 4 * c) : zero4;
+            const int sres = a.S[grow];
+            uv4 ra = *reinterpret_cast<const uv4 *>(a.hA + grow * TM_H + 4 * c);
+            uv4 rb = *reinterpret_cast<const uv4 *>(a.hB + grow * TM_H + 4 * c);
+            const f4 vs = ld4(a.Ws + (ok ? sres : 0) * TM_H + 4 * c);
+            if (!ok) { ra = zero4; rb = zero4; }
             bool bad = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) bad = bad || tm_nonfinite_bits(ra[k]) || tm_nonfinite_bits(rb[k]);
@@ -223,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
             const f4 va = __builtin_bit_cast(f4, ra), vb = __builtin_bit_cast(f4, rb);
             store_split<SP, ROWS>(pX[0], row, c, va);
             store_split<SP, ROWS>(pX[1], row, c, vb);
-            store_split<SP, ROWS>(pX[2], row, c, ld4(a.Ws + (ok ? a.S[r0 + row] : 0) * TM_H + 4 * c));
+            store_split<SP, ROWS>(pX[2], row, c, vs);
         }
         __syncthreads();
 
@@ -231,11 +253,8 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
 #pragma unroll 1
         for (int g = 0; g < 3; ++g) {
             f4 acc[NRB][1];
-            {
-                const f4 b = ld4(a.conv_b + 128 * g + ncol);
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
-            }
+            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = g == 0 ? cb[0] : g == 1 ? cb[1] : cb[2];
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
                 split_raw();
@@ -250,11 +269,8 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
 
         if (wv < 4) {   // 384 -> 64, relu; wavefront w owns columns 16w..16w+15 -> tF0[:, 0:64] (x planes are dead)
             f4 acc[NRB][1];
-            {
-                const f4 b = ld4(a.b1 + ncol);
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
-            }
+            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b1v;
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
                 split_raw();
@@ -268,11 +284,8 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
         __syncthreads();
         if (wv < 2) {   // 64 -> 32, relu -> tF1[:, 0:32]
             f4 acc[NRB][1];
-            const f4 b = ld4(a.b2 + ncol);
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
-            float w32[1][16];
-            load_wfrag<4>(a.w2, 64, 16 * wv, 0, 32, w32[0], lane);
+            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b2v;
             mma_tile<4, 1, 128, NRB>(tF0, w32, acc, lane);
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) st4(tF1 + chunk_off(16 * rb + m, c4), relu4(acc[rb][0]));
@@ -280,16 +293,8 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
         __syncthreads();
         if (wv < 2) {   // 32 -> 21 (rows 21..31 of the weight read as zero) -> z in tF2[:, 0:32]
             f4 acc[NRB][1];
-            f4 b;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = ncol + r;
-                b[r] = n < TMPNN_VOCAB ? a.b3[n] : 0.f;
-            }
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
-            float w8[1][8];
-            load_wfrag<2>(a.w3, 32, 16 * wv, 0, TMPNN_VOCAB, w8[0], lane);
+            for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b3v;
             mma_tile<2, 1, 128, NRB>(tF1, w8, acc, lane);
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) st4(tF2 + chunk_off(16 * rb + m, c4), acc[rb][0]);
