@@ -258,6 +258,8 @@ struct FeatArgs {
     float *hE, *E_opt;
     int T;
     float mu[16];            // torch.linspace(2, 22, 16)
+    const char *img_e[4];    // fragment images of edge_embedding.weight[:, 16:416] (four 128-column blocks, the last zero-padded) ...
+    const char *img_we;      // ... and of W_e (f16x2 handles; null otherwise)
 };
 
 __device__ __forceinline__ void atoms5(const float *__restrict__ x, float *out /*[15]*/) {
@@ -410,8 +412,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 1)) void featurize_kernel(F
 // fp32 output tile — are aliased on the dead RBF planes.
 // ------------------------------------------------------------------------------------------------
 #define RBFP_ROWB 1024
+#ifndef TM_FEAT_PF
+#define TM_FEAT_PF 1      // B-fragment prefetch distance of GEMM 1 (mma_tile_split): 1 = 0.500 ms with 38 spilled VGPRs (reloaded around the GEMM, not in it) against 0.524 at 0 (13 spilled), 0.527 at 2
+#endif
 // PROF: phase timing (s_memtime deltas of thread 0 of workgroup 0, summed over its tiles) into prof[0..7] — TMPNN_FEAT_PROF=1
-template <typename SP, bool PROF = false>
+template <typename SP, bool PROF = false, bool IMG = false>
 __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, unsigned long long *prof = nullptr) {
     unsigned long long t_last = 0;
     auto mark = [&](int k) {
@@ -437,9 +442,28 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
     const int c32 = lane & 31;
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
 
+    // Weight fragments, resident for the whole launch (136 VGPRs). With fragment images (f16x2 handles) they arrive as coalesced
+    // 1 KB loads instead of 16-row fp32 gathers split on the fly (the prologue is what a single protein pays for). Re-reading
+    // W_e per tile instead of keeping it (to free 32 VGPRs for the GEMM-1 pipeline) was measured twice: 64 KB per tile through
+    // the CU's 64 B/clk return path costs more than the pipeline gains (0.546 vs 0.534 ms).
     WFragS<SP> wedge[1][13], we[1][4];
-    load_wfrag_split<SP, 13>(a.edge_w, 416, 16 * wv, 16, 400, wedge[0], lane);
-    load_wfrag_split<SP, 4>(a.We_w, TM_H, 16 * wv, 0, TM_H, we[0], lane);
+    if constexpr (IMG) {
+#pragma unroll
+        for (int st = 0; st < 13; ++st) {
+            const char *p = a.img_e[st >> 2] + (size_t)wv * 8192 + (st & 3) * 2048 + lane * 16;
+            wedge[0][st].p[0] = *reinterpret_cast<const u4 *>(p);
+            wedge[0][st].p[1] = *reinterpret_cast<const u4 *>(p + 1024);
+        }
+        const char *pw = a.img_we + (size_t)wv * 8192 + lane * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            we[0][c].p[0] = *reinterpret_cast<const u4 *>(pw + 2048 * c);
+            we[0][c].p[1] = *reinterpret_cast<const u4 *>(pw + 2048 * c + 1024);
+        }
+    } else {
+        load_wfrag_split<SP, 13>(a.edge_w, 416, 16 * wv, 16, 400, wedge[0], lane);
+        load_wfrag_split<SP, 4>(a.We_w, TM_H, 16 * wv, 0, TM_H, we[0], lane);
+    }
     const f4 be = ld4(a.We_b + ncol);
     const f4 g4 = ld4(a.ln_w + ncol), b4 = ld4(a.ln_b + ncol);
     f4 mu4;                                                   // this thread's 4 Gaussian centres: (tid & 3) is fixed
@@ -536,7 +560,7 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_dpos[cur][16 * rb + m] * TM_H + ncol);
-        mma_tile_split<SP, 13, 1, 3, TM_TILE, RBFP_ROWB, 13, 0, true>(rbf, wedge, acc, lane);
+        mma_tile_split<SP, 13, 1, 3, TM_TILE, RBFP_ROWB, 13, 0, true, TM_FEAT_PF>(rbf, wedge, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) row_stats_partial1b(acc[rb][0], &s_stat[16 * rb + m][2 * wv], q);
         mark(2);
@@ -710,6 +734,12 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
     a.hE = h_E; a.E_opt = E_opt; a.T = (int)T;
     for (int i = 0; i < 16; ++i)   // torch.linspace(2, 22, 16): double arithmetic, symmetric halves, cast to fp32
         a.mu[i] = i < 8 ? (float)(2.0 + (20.0 / 15.0) * i) : (float)(22.0 - (20.0 / 15.0) * (15 - i));
+    bool img = tm_matmul_mode() == TM_MM_F16X2;
+    for (int b = 0; b < 4; ++b) { a.img_e[b] = img ? tm_find_wimg(w->edge_w + 16 + 128 * b) : nullptr; img = img && a.img_e[b]; }
+    a.img_we = img ? tm_find_wimg(w->We_w) : nullptr;
+    img = img && a.img_we;
+    static const bool img_off = [] { const char *e = getenv("TMPNN_FEAT_IMG"); return e != nullptr && e[0] == '0'; }();
+    if (img_off) img = false;
     const int64_t cap = tm_num_cus();
     static const int nw = [] { const char *e = getenv("TMPNN_FEAT_WAVES"); return e ? atoi(e) : 8; }();
     // (two split-precision bf16x3 forms of this kernel — half-width tiles, and one 126 KB single-pass plane tile — were
@@ -722,7 +752,8 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
         static unsigned long long *d_prof = nullptr;
         if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
         (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
-        featurize_split_kernel<SplitH2, true><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a, d_prof);
+        if (img) featurize_split_kernel<SplitH2, true, true><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a, d_prof);
+        else featurize_split_kernel<SplitH2, true><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a, d_prof);
         unsigned long long h[16];
         (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
         fprintf(stderr, "featurize phases (100 MHz ticks, wg 0): gauss %llu bar %llu gemm1+stats %llu publish %llu bar %llu ln+split %llu dist %llu bar %llu gemm2 %llu bar %llu store %llu\n",
@@ -731,7 +762,8 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
         return tm_check_launch("edge_featurize");
     }
     if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
-        featurize_split_kernel<SplitH2><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
+        if (img) featurize_split_kernel<SplitH2, false, true><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
+        else featurize_split_kernel<SplitH2><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
         tm_prof_end(st);
         return tm_check_launch("edge_featurize");
     }

@@ -19,7 +19,7 @@ struct DecW {
 // [wavefront 8][k-step 4][plane 2][lane 64] x 16 B — a wavefront's fragment is four coalesced 1 KB loads per plane
 // instead of 16-row gathers of fp32 that are split on the fly (tmpnn_split.hip: node_update8_split_kernel).
 #define TM_WIMG_BYTES 65536
-#define TM_N_WIMG 105          // enc: W3 + 4 W_in + 4 W_out + W1a W1c W11a W11c + W1e W2 W11e W12 W13 (18) x 3; dec: W3 + 4 + 4 + W1a W1d + W1e W2 (13) x 3; head: 9 blocks of the centre tap + 3 of both_out.1
+#define TM_N_WIMG 110          // enc: W3 + 4 W_in + 4 W_out + W1a W1c W11a W11c + W1e W2 W11e W12 W13 (18) x 3; dec: W3 + 4 + 4 + W1a W1d + W1e W2 (13) x 3; head: 9 blocks of the centre tap + 3 of both_out.1; featurizer: 4 blocks of W_edge[:, 16:416] + W_e
 struct WImg { const float *base; const char *img; };      // base = address of the block's element [0][0] in the raw tensor
 
 struct tmpnn_weights {
@@ -119,7 +119,7 @@ struct TmModeScope {                  // entry points that take a handle open on
     explicit TmModeScope(const tmpnn_weights *w);
     ~TmModeScope();
 };
-int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st, int n_rows = 128);       // tmpnn_split.hip
+int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st, int n_rows = 128, int k_valid = 128);       // tmpnn_split.hip
 const char *tm_find_wimg(const float *base);                                   // nullptr if no image (or no handle in scope)
 // Non-finite tests under -fno-honor-nans. The kernels are built with relaxed NaN semantics, so hipcc may fold a NaN test
 // on the RESULT of floating-point arithmetic (measured: both the sum test and the exponent-bit test on a computed value
