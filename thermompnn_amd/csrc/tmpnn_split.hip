@@ -7,7 +7,7 @@
 #include "tmpnn_split.h"
 
 #ifndef TM_EDGE_PF
-#define TM_EDGE_PF 0     // the same for the edge-update kernel (measured: its three 12-step GEMMs gain nothing, 0.379 vs 0.386 ms)
+#define TM_EDGE_PF 2     // the same for the edge-update kernel's three 12-step GEMMs: 0.339 ms at 0, 0.329 at 1, 0.323 at 2, 0.326 at 3-4
 #endif
 #ifndef TM_NODE_PF
 #define TM_NODE_PF 3
