@@ -527,10 +527,18 @@ __global__ __launch_bounds__(512, 2) void msg8_split_kernel(MsgArgsB a) {
             if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
             st4(tS + chunk_off(16 * rb + m, c4), v);
         }
-        if (tid == 128) {                                        // neighbour count of this tile (read before s_ma[cur] is recycled)
-            float c = 0.f;
-            for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
-            a.cnt[i] = c;
+        if (wv == 2) {                                           // neighbour count of this tile (read before s_ma[cur] is recycled):
+            float c = lane < TM_TILE ? s_ma[cur][lane] : 0.f;    // one wavefront-wide DPP sum (a serial 48-term loop in one lane
+#define TM_DPP_ADD(ctrl, row_mask, bc)                                                                  \
+            c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), ctrl, row_mask, 0xf, bc));
+            TM_DPP_ADD(0x111, 0xf, true)                         // held the other seven wavefronts at the barrier for ~350 cycles)
+            TM_DPP_ADD(0x112, 0xf, true)
+            TM_DPP_ADD(0x114, 0xf, true)
+            TM_DPP_ADD(0x118, 0xf, true)                         // lane 15 of every row: the row's sum
+            TM_DPP_ADD(0x142, 0xa, false)                        // row_bcast:15 into rows 1 and 3
+            TM_DPP_ADD(0x143, 0xc, false)                        // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef TM_DPP_ADD
+            if (lane == 63) a.cnt[i] = c;
         }
         __syncthreads();
         {   // per-node aggregation: column sums over 4 row groups of 12, combined in a fixed order
@@ -681,10 +689,18 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
             for (int rb = 0; rb < 3; ++rb) touch(gj[rb]);
         }
         if (m == 15) st4(a.Ssum + (size_t)i * TM_H + ncol, tot);
-        if (tid == 128) {                                        // neighbour count of this tile (read before s_ma[cur] is recycled)
-            float c = 0.f;
-            for (int r = 0; r < TM_TILE; ++r) c += s_ma[cur][r];
-            a.cnt[i] = c;
+        if (wv == 2) {                                           // neighbour count of this tile (read before s_ma[cur] is recycled):
+            float c = lane < TM_TILE ? s_ma[cur][lane] : 0.f;    // one wavefront-wide DPP sum (a serial 48-term loop in one lane
+#define TM_DPP_ADD(ctrl, row_mask, bc)                                                                  \
+            c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), ctrl, row_mask, 0xf, bc));
+            TM_DPP_ADD(0x111, 0xf, true)                         // held the other seven wavefronts at the barrier for ~350 cycles)
+            TM_DPP_ADD(0x112, 0xf, true)
+            TM_DPP_ADD(0x114, 0xf, true)
+            TM_DPP_ADD(0x118, 0xf, true)                         // lane 15 of every row: the row's sum
+            TM_DPP_ADD(0x142, 0xa, false)                        // row_bcast:15 into rows 1 and 3
+            TM_DPP_ADD(0x143, 0xc, false)                        // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef TM_DPP_ADD
+            if (lane == 63) a.cnt[i] = c;
         }
         mark(5);
         mark(6);
