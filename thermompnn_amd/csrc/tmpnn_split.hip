@@ -299,18 +299,23 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         for (int rb = 0; rb < 3; ++rb) touch(gcj[rb]);
         __syncthreads();
     }
+    // neighbour list of the NEXT tile: requested one whole iteration before it is published (after GEMM 1 of the iteration
+    // that precedes its tile) — wavefront 0 used to sit on that load in front of the barrier the other seven were waiting at
+    int nidx = -1;
+    if (i < tr.end && tid < TM_TILE) nidx = a.E_idx[(size_t)(i + tr.step < tr.end ? i + tr.step : i) * TM_KS + tid];
     mark(-1);
     for (; i < tr.end; i += tr.step) {
         float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
         const int inext = i + tr.step;
         const bool has_next = inext < tr.end;
         const int ipf = has_next ? inext : i;              // prefetch target (the last iteration re-reads its own tile)
-        int nidx = -1;
+        const int ipf2 = ipf + tr.step < tr.end ? ipf + tr.step : ipf;
+        const int nidx_pub = nidx;                         // list of tile ipf, requested during the previous iteration
         {
+            if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf2 * TM_KS + tid];
             const float *src = a.hE + (size_t)ipf * TM_KS * TM_H + ncol;
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = ld4(src + (16 * rb + m) * TM_H);
-            if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf * TM_KS + tid];
         }
         f4 acc[3][1];
 #pragma unroll
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) store_split<SP>(tX, 16 * rb + m, c4, g[rb]);
         }
-        if (tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx;
+        if (tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx_pub;
         mark(1);
         __syncthreads();
         mark(2);
