@@ -748,13 +748,28 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
 // is requested before the MFMAs of GEMM u and split into f16 planes after them, so no GEMM waits on an L2 round trip
 // (the 4-wavefront form above does, 13 times per tile); the taller tile halves the weight traffic per residue.
 // ------------------------------------------------------------------------------------------------
-template <typename SP, int NRB, bool IMG>
-__global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) {
+template <typename SP, int NRB, bool IMG, bool PROF = false>
+__global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, unsigned long long *prof = nullptr) {
+    int n_mark = 0;
+    auto mark = [&]() {                 // TMPNN_NODE_PROF=1: cycle stamps of thread 0 of workgroup 0 at every stage boundary (first tile)
+        if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && n_mark < 32) prof[n_mark++] = __builtin_readcyclecounter();
+    };
+    mark();
     constexpr int ROWS = 16 * NRB, PLT = SP::NP * ROWS * 256;
     static_assert(PLT >= ROWS * TM_H * 4, "the fp32 LayerNorm-2 input is aliased on the plane tile pA");
     __shared__ __attribute__((aligned(16))) char pA[PLT];
     __shared__ __attribute__((aligned(16))) char pB[PLT];
     __shared__ __attribute__((aligned(16))) float tB[ROWS * TM_H];
+    // Every small operand of the tile comes from LDS: the layer's bias / LayerNorm vectors and the sequence tables once per
+    // workgroup, the tile's own rows (old state into tB, neighbour counts, masks, table indices) with the tile's first loads.
+    // gfx9 retires loads and stores in order: a bias fetched from global memory at an accumulator initialisation waited for
+    // the 64 KB weight fragment requested just before it and for the previous unit's 32 KB of stores — stage timers showed
+    // 5 k cycles per W_in unit against 2.3 k per W_out unit (no bias) and 9 k per projection half (stores + bias).
+    enum { P_B3 = 0, P_BOUT = 128, P_BIN = 256, P_N1W = 768, P_N1B = 896, P_N2W = 1024, P_N2B = 1152, P_BA = 1280, P_END = 1536 };
+    __shared__ __attribute__((aligned(16))) float s_par[P_END];
+    __shared__ __attribute__((aligned(16))) float s_add[2][TMPNN_VOCAB * TM_H];
+    __shared__ float s_cnt[ROWS], s_mask[ROWS];
+    __shared__ int s_aidx[2][ROWS];
     float *tA = reinterpret_cast<float *>(pA);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31, hw = tid >> 5;                  // half-wavefront index: rows hw*NRB .. hw*NRB + NRB - 1
@@ -821,15 +836,80 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
     const int first_proj = has0 ? 9 : 11;                       // first projection unit, if any
 
     int tile = blockIdx.x;
-    if (tile < n_tiles) issue(0);
+    if (tile >= n_tiles) return;
+    {   // every load unconditional and requested before the first LDS write (a load under a branch is waited for at the join:
+        // written the obvious way this block was seven dependent round trips, 9 k cycles)
+        const int t7 = tid & 127;
+        const bool hp0 = a.proj[0].P != nullptr, hp1 = a.proj[1].P != nullptr;
+        const float *ba0 = hp0 ? a.proj[0].ba : a.b3, *ba1 = hp1 ? a.proj[1].ba : a.b3;
+        const bool ha0 = hp0 && a.proj[0].add_tab != nullptr, ha1 = hp1 && a.proj[1].add_tab != nullptr;
+        const float *at0 = ha0 ? a.proj[0].add_tab : a.bin, *at1 = ha1 ? a.proj[1].add_tab : a.bin;     // (dummies: any 512 valid floats)
+        const float vbin = a.bin[tid];
+        const float v6[8] = {a.b3[t7], a.bout[t7], a.n1w[t7], a.n1b[t7], a.n2w[t7], a.n2b[t7], ba0[t7], ba1[t7]};
+        constexpr int NADD = (TMPNN_VOCAB * TM_H + 511) / 512;
+        float va[2][NADD];
+#pragma unroll
+        for (int j = 0; j < NADD; ++j) {
+            const int e = tid + 512 * j;
+            va[0][j] = at0[ha0 && e < TMPNN_VOCAB * TM_H ? e : tid];
+            va[1][j] = at1[ha1 && e < TMPNN_VOCAB * TM_H ? e : tid];
+        }
+        s_par[P_BIN + tid] = vbin;
+        if (tid < 128) {
+            s_par[P_B3 + tid] = v6[0];
+            s_par[P_BOUT + tid] = v6[1];
+            s_par[P_N1W + tid] = v6[2];
+            s_par[P_N1B + tid] = v6[3];
+            s_par[P_N2W + tid] = v6[4];
+            s_par[P_N2B + tid] = v6[5];
+            s_par[P_BA + tid] = v6[6];
+            s_par[P_BA + 128 + tid] = v6[7];
+        }
+#pragma unroll
+        for (int j = 0; j < NADD; ++j) {
+            const int e = tid + 512 * j;
+            if (e < TMPNN_VOCAB * TM_H) {
+                s_add[0][e] = va[0][j];
+                s_add[1][e] = va[1][j];
+            }
+        }
+    }
+    mark();
+    issue(0);
     for (; tile < n_tiles; tile += gridDim.x) {
         const int r0 = tile * ROWS;
-        for (int idx = tid; idx < ROWS * 32; idx += 512) {      // aggregated messages -> planes
-            const int row = idx >> 5, c = idx & 31;
-            const f4 v = r0 + row < a.T ? ld4(a.Ssum + (size_t)(r0 + row) * TM_H + 4 * c) : f4{0.f, 0.f, 0.f, 0.f};
-            store_split<SP, ROWS>(pA, row, c, v);
+        {   // aggregated messages -> planes, old state -> tB: all 2 NRB row chunks of this thread requested before the first is used
+            static_assert(ROWS * 32 == 512 * NRB, "one 16-byte chunk of NRB rows per thread");
+            f4 v[NRB], hvv[NRB];
+#pragma unroll
+            for (int it = 0; it < NRB; ++it) {
+                const int row = 16 * it + (tid >> 5), c = tid & 31;
+                const size_t g = (size_t)(r0 + row < a.T ? r0 + row : r0) * TM_H + 4 * c;   // (rows past T: a valid row, zeroed below)
+                v[it] = ld4(a.Ssum + g);
+                hvv[it] = ld4(a.h_in + g);
+            }
+#pragma unroll
+            for (int it = 0; it < NRB; ++it) {
+                const int row = 16 * it + (tid >> 5), c = tid & 31;
+                const bool ok = r0 + row < a.T;
+                const f4 z4 = f4{0.f, 0.f, 0.f, 0.f};
+                store_split<SP, ROWS>(pA, row, c, ok ? v[it] : z4);
+                st4(tB + chunk_off(row, c), ok ? hvv[it] : z4);
+            }
+        }
+        mark();
+        if (tid < ROWS) {
+            const bool ok = r0 + tid < a.T;
+            const int g = ok ? r0 + tid : r0;
+            const float cv = a.cnt[g], mv = a.mask[g];
+            s_cnt[tid] = ok ? cv : 0.f;
+            s_mask[tid] = ok ? mv : 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (a.proj[k].P != nullptr && a.proj[k].add_tab != nullptr) s_aidx[k][tid] = ok ? a.proj[k].add_idx[g] : 0;
         }
         __syncthreads();
+        mark();
 
         f4 acc[NRB][1];
         split_raw();
@@ -838,20 +918,20 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
         for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = f4{0.f, 0.f, 0.f, 0.f};
         mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pA, wf, acc, lane);
         {
-            const f4 b3 = ld4(a.b3 + ncol);
+            const f4 b3 = ld4(s_par + P_B3 + ncol);
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                const int row = r0 + 16 * rb + m;
-                const bool ok = row < a.T;
-                const float c = ok ? a.cnt[row] : 0.f;
-                const f4 hv = ok ? ld4(a.h_in + (size_t)row * TM_H + ncol) : f4{0.f, 0.f, 0.f, 0.f};
+                float *p = tB + chunk_off(16 * rb + m, c4);      // holds the old state of (row, these 4 columns): this thread's own slot
+                const float c = s_cnt[16 * rb + m];
+                const f4 hv = ld4(p);
                 const f4 dh = fma4s(c, b3, acc[rb][0]) / 30.0f;
-                st4(tB + chunk_off(16 * rb + m, c4), hv + dh);
+                st4(p, hv + dh);
             }
         }
         __syncthreads();
+        mark();
         {   // LN1: fp32 in place (the FFN residual) + planes (the FFN input)
-            const f4 g4 = ld4(a.n1w + 4 * c32), b4 = ld4(a.n1b + 4 * c32);
+            const f4 g4 = ld4(s_par + P_N1W + 4 * c32), b4 = ld4(s_par + P_N1B + 4 * c32);
 #pragma unroll
             for (int it = 0; it < NRB; ++it) {
                 const int row = NRB * hw + it;
@@ -862,10 +942,11 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
             }
         }
         __syncthreads();
+        mark();
 
         f4 out[NRB][1];
         {
-            const f4 b = ld4(a.bout + ncol);
+            const f4 b = ld4(s_par + P_BOUT + ncol);
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) out[rb][0] = b;
         }
@@ -874,7 +955,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
             split_raw();                        // W_in chunk c
             issue(2 + 2 * c);
             {
-                const f4 b = ld4(a.bin + 128 * c + ncol);
+                const f4 b = ld4(s_par + P_BIN + 128 * c + ncol);
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
             }
@@ -882,12 +963,14 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) store_split<SP, ROWS>(pA, 16 * rb + m, c4, gelu4(acc[rb][0]));
             __syncthreads();
+            mark();
             split_raw();                        // W_out chunk c
             if (c < 3) issue(3 + 2 * c);
             else if (has0 || has1) issue(first_proj);
             else if (tile + (int)gridDim.x < n_tiles) issue(0);
             mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pA, wf, out, lane);
             __syncthreads();
+            mark();
         }
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
@@ -896,18 +979,19 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
         }
         __syncthreads();
         {   // LN2, mask, coalesced store; the new state goes into the planes pB for the projections
-            const f4 g4 = ld4(a.n2w + 4 * c32), b4 = ld4(a.n2b + 4 * c32);
+            const f4 g4 = ld4(s_par + P_N2W + 4 * c32), b4 = ld4(s_par + P_N2B + 4 * c32);
 #pragma unroll
             for (int it = 0; it < NRB; ++it) {
                 const int row = NRB * hw + it;
                 const int grow = r0 + row;
                 f4 y = layer_norm_row(ld4(tA + chunk_off(row, c32)), g4, b4);
-                y = grow < a.T ? y * a.mask[grow] : f4{0.f, 0.f, 0.f, 0.f};
+                y = grow < a.T ? y * s_mask[row] : f4{0.f, 0.f, 0.f, 0.f};
                 store_split<SP, ROWS>(pB, row, c32, y);
                 if (grow < a.T) st4(a.h_out + (size_t)grow * TM_H + 4 * c32, y);
             }
         }
         __syncthreads();
+        mark();
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const ProjSpec &ps = a.proj[k];
@@ -920,7 +1004,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
                 else if (k == 0 && has1) issue(11);
                 else if (tile + (int)gridDim.x < n_tiles) issue(0);
                 {
-                    const f4 b = half ? f4{0.f, 0.f, 0.f, 0.f} : ld4(ps.ba + ncol);
+                    const f4 b = half ? f4{0.f, 0.f, 0.f, 0.f} : ld4(s_par + P_BA + 128 * k + ncol);
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
                 }
@@ -929,10 +1013,11 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a) 
                 for (int rb = 0; rb < NRB; ++rb) {
                     const int row = r0 + 16 * rb + m;
                     if (row < a.T) {
-                        const float *add = half && ps.add_tab ? ps.add_tab + ps.add_idx[row] * TM_H : nullptr;
+                        const float *add = half && ps.add_tab ? s_add[k] + s_aidx[k][16 * rb + m] * TM_H : nullptr;
                         st4(ps.P + (size_t)row * 256 + 128 * half + ncol, add ? ld4(add + ncol) + acc[rb][0] : acc[rb][0]);
                     }
                 }
+                mark();
             }
         }
         __syncthreads();
@@ -1172,6 +1257,19 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
         else if (np == 1) node_update8_deep_kernel<1, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
         else node_update8_deep_kernel<2, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
         return tm_check_launch("node_update8_deep");
+    }
+    static const bool prof4 = [] { const char *e = getenv("TMPNN_NODE_PROF"); return e != nullptr && e[0] == '1'; }();
+    if (prof4 && a.img[0] && best_rows == 64) {                 // debug: stage stamps of workgroup 0 (synchronises!)
+        static unsigned long long *d_prof = nullptr;
+        if (!d_prof) (void)hipMalloc(&d_prof, 32 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), st);
+        node_update8_split_kernel<SplitH2, 4, true, true><<<grid, 512, 0, st>>>(a, d_prof);
+        unsigned long long h[32];
+        (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "node_update8 (64 rows) stages (cycles since entry, wg 0):");
+        for (int k = 1; k < 20 && h[k]; ++k) fprintf(stderr, " %llu", h[k] - h[0]);
+        fprintf(stderr, "\n");
+        return tm_check_launch("node_update8_split");
     }
 #define TM_NODE8(NRB)                                                                    \
     if (a.img[0]) node_update8_split_kernel<SplitH2, NRB, true><<<grid, 512, 0, st>>>(a); \
