@@ -6,6 +6,9 @@
 
 #include "tmpnn_split.h"
 
+#ifndef TM_PROF_TID
+#define TM_PROF_TID 0   // thread of workgroup 0 whose cycle counter the TMPNN_*_PROF phase timers read (448 = wavefront 7, lowest issue priority)
+#endif
 #ifndef TM_EDGE_PF
 #define TM_EDGE_PF 2     // the same for the edge-update kernel's three 12-step GEMMs: 0.339 ms at 0, 0.329 at 1, 0.323 at 2, 0.326 at 3-4
 #endif
@@ -251,7 +254,7 @@ template <typename SP, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsigned long long *prof = nullptr) {
     unsigned long long t_last = 0;
     auto mark = [&](int k) {           // TMPNN_EDGE_PROF=1: phase timing of thread 0 of workgroup 0
-        if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (PROF && blockIdx.x == 0 && threadIdx.x == TM_PROF_TID) {
             const unsigned long long t = __builtin_readcyclecounter();
             if (k >= 0) prof[k] += t - t_last;
             t_last = t;
@@ -568,7 +571,7 @@ template <typename SP, bool DEC, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned long long *prof = nullptr) {
     unsigned long long t_last = 0;
     auto mark = [&](int k) {           // TMPNN_MSG_PROF=1: phase timing of thread 0 of workgroup 0
-        if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (PROF && blockIdx.x == 0 && threadIdx.x == TM_PROF_TID) {
             const unsigned long long t = __builtin_readcyclecounter();
             if (k >= 0) prof[k] += t - t_last;
             t_last = t;
@@ -1046,7 +1049,7 @@ __global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsi
     using SP = SplitH2;
     int n_mark = 0;
     auto mark = [&]() {                 // TMPNN_NODE_PROF=1: cycle stamps of thread 0 of workgroup 0 at every stage boundary
-        if (PROF && blockIdx.x == 0 && threadIdx.x == 0) prof[n_mark++] = __builtin_readcyclecounter();
+        if (PROF && blockIdx.x == 0 && threadIdx.x == TM_PROF_TID) prof[n_mark++] = __builtin_readcyclecounter();
     };
     mark();
     kernarg_warm<sizeof(NodeArgs)>();
