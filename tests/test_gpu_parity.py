@@ -539,8 +539,9 @@ def test_precision_default_comes_from_the_environment():
     assert bad.returncode != 0 and "unknown precision" in bad.stderr      # an error, not an abort()
 
 
-@pytest.mark.parametrize("env", [{"TMPNN_NODE_SPLIT": "0", "TMPNN_FEAT_SPLIT": "0", "TMPNN_HEAD_SPLIT": "0"}, {"TMPNN_NODE_IMG": "0"}],
-                         ids=["fp32_node_featurizer_head", "no_weight_fragment_images"])
+@pytest.mark.parametrize("env", [{"TMPNN_NODE_SPLIT": "0", "TMPNN_FEAT_SPLIT": "0", "TMPNN_HEAD_SPLIT": "0"},
+                                 {"TMPNN_NODE_IMG": "0", "TMPNN_FEAT_IMG": "0"}, {"TMPNN_NODE_DEEP": "0", "TMPNN_KNN_REG": "0"}],
+                         ids=["fp32_node_featurizer_head", "no_weight_fragment_images", "tall_node_tiles_and_lds_knn_for_small_launches"])
 def test_selectable_kernel_forms_pass_golden_parity(env):
     """The non-default kernel forms of the f16x2 mode (selected by environment, read once per process) stay parity-green."""
     import subprocess
