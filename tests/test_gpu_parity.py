@@ -553,6 +553,21 @@ def test_selectable_kernel_forms_pass_golden_parity(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_small_launch_kernel_forms_are_bit_identical():
+    """Which form of a kernel runs depends on the launch size (register k-NN rows for proteins up to 512 residues, the deep-prefetch
+    node_update when every workgroup has one 16-row tile): the forms must agree BIT FOR BIT, or a protein's result would depend
+    on the batch it is in. tools/dbg_knn.py (ties, masked residues, L < K, ragged batches) and tools/dbg_deep.py run both forms
+    in separate processes and compare the raw bits."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(GOLDEN.rstrip("/")))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "dbg_knn.py")], cwd=repo, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL IDENTICAL" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "dbg_deep.py")], cwd=repo, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if "max diff" in l]
+    assert r.returncode == 0 and len(lines) == 3 and all("n diff 0 " in l for l in lines), r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_f16x2_range_limit_is_loud():
     """f16x2 needs |x| < 65504: beyond it the GEMM core returns inf/nan (never a silently wrong finite number);
     bf16x3 and fp32 keep the full fp32 range."""
