@@ -6,6 +6,9 @@
 
 #include "tmpnn_split.h"
 
+#ifndef TM_SETPRIO
+#define TM_SETPRIO 1   // s_setprio 1 for wavefronts 4-7 of the per-edge kernels (VALU arbitration is by age: the second-dispatched half loses it): about -0.8 %
+#endif
 #ifndef TM_PROF_TID
 #define TM_PROF_TID 0   // thread of workgroup 0 whose cycle counter the TMPNN_*_PROF phase timers read (448 = wavefront 7, lowest issue priority)
 #endif
@@ -279,6 +282,9 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     const f4 b12 = ld4(a.b12 + ncol), b13 = ld4(a.b13 + ncol);
     const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
 
+#if TM_SETPRIO
+    if (wv >= 4) __builtin_amdgcn_s_setprio(1);    // the second-dispatched half loses every VALU arbitration by age: static priority evens it out
+#endif
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin;
     int cur = 0;
@@ -620,6 +626,9 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         for (int it = 0; it < 3; ++it) store_split<SP>(tE, prow + 2 * it, pc, e_nxt[it]);
     };
 
+#if TM_SETPRIO
+    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin;
     int cur = 0;
