@@ -7,7 +7,7 @@
 #include "tmpnn_split.h"
 
 #ifndef TM_SETPRIO
-#define TM_SETPRIO 1   // s_setprio 1 for wavefronts 4-7 of the per-edge kernels (VALU arbitration is by age: the second-dispatched half loses it): about -0.8 %
+#define TM_SETPRIO 0   // 1: s_setprio 1 for wavefronts 4-7 of the per-edge kernels (VALU arbitration is by age; the guide reports -0.8..-1.5 % for an attention loop). Measured here with a provably wave-uniform condition: +2.5 % message kernels, +2 % edge update - off
 #endif
 #ifndef TM_PROF_TID
 #define TM_PROF_TID 0   // thread of workgroup 0 whose cycle counter the TMPNN_*_PROF phase timers read (448 = wavefront 7, lowest issue priority)
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
 
 #if TM_SETPRIO
-    if (wv >= 4) __builtin_amdgcn_s_setprio(1);    // the second-dispatched half loses every VALU arbitration by age: static priority evens it out
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);    // (provably wave-uniform condition: s_setprio ignores EXEC)
 #endif
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin;
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     };
 
 #if TM_SETPRIO
-    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 #endif
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin;
