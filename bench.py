@@ -425,6 +425,8 @@ def main():
         lat = latency(fwd1)
         result["single_protein"] = {"ms": lat * 1e3, "preds_per_s": L * 20 / lat}
         try:
+            if world > 1:     # no stream capture next to a live RCCL communicator (its watchdog thread's event queries can invalidate one)
+                raise RuntimeError("hipGraph leg skipped in multi-rank runs; measured in the 1-GPU run")
             graph, _ = eng.capture_graph(one["X"], one["S"], one["mask"], one["ridx"], one["cenc"], one["offsets"], max_len=L, out=o1)
             ref = o1["ddg"].clone()
             lat_g = latency(graph.replay)
