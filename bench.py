@@ -322,7 +322,7 @@ def main():
     # Forward only, NO collective: the loop is bounded by each rank's own clock, so ranks run different numbers of
     # iterations — a collective in here deadlocks intermittently (caught by tests/test_gpu_parity.py::test_two_rank_bench_and_cli).
     # (TMPNN_BENCH_WARMUP_SKEW=1, test hook: rank r warms up (1 + r) x as long, so the iteration counts differ for certain)
-    warm_s = 0.3 * (1 + rank if os.environ.get("TMPNN_BENCH_WARMUP_SKEW") == "1" else 1)
+    warm_s = float(os.environ.get("TMPNN_BENCH_CLOCK_WARMUP_S", "0.3")) * (1 + rank if os.environ.get("TMPNN_BENCH_WARMUP_SKEW") == "1" else 1)
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < warm_s:
         step(gather=False)
