@@ -31,6 +31,10 @@ from thermompnn_amd.weights import (save_vanilla_checkpoint, split_transfer_stat
                                     synthetic_state_dict)
 
 WEIGHT_SEED = 0
+# further weight sets through the SAME imported reference: (fixture suffix, seed, style). The released checkpoints are absent
+# from the mount, so the only guard for the split-precision accuracy margin is a second Xavier draw and a deliberately heavy
+# ("hot") draw: matrices x 3, biases x 5, LayerNorm gamma in [-2, 2] (thermompnn_amd.weights._draw).
+EXTRA_WEIGHT_SETS = (("w1", 1, "xavier"), ("hot", 2, "hot"))
 
 
 class AD(dict):
@@ -38,10 +42,10 @@ class AD(dict):
     __setattr__ = dict.__setitem__
 
 
-def build_reference_model(tmp):
-    sd = synthetic_state_dict(WEIGHT_SEED)
+def build_reference_model(tmp, seed=WEIGHT_SEED, style="xavier"):
+    sd = synthetic_state_dict(seed, style=style)
     mp, _ = split_transfer_state_dict(sd)
-    os.makedirs(os.path.join(tmp, "vanilla_model_weights"))
+    os.makedirs(os.path.join(tmp, "vanilla_model_weights"), exist_ok=True)
     save_vanilla_checkpoint(os.path.join(tmp, "vanilla_model_weights", "v_48_020.pt"), mp, 48)
     cfg = AD(model=AD(hidden_dims=[64, 32], subtract_mut=True, num_final_layers=2, freeze_weights=True,
                       load_pretrained=True, lightattn=True), platform=AD(thermompnn_dir=tmp))
@@ -51,7 +55,7 @@ def build_reference_model(tmp):
     return model.eval()
 
 
-def run_case(model, pdb, trace_level):
+def run_case(model, pdb, trace_level, seed=WEIGHT_SEED, style="xavier"):
     """trace_level: 2 = every layer, 1 = last encoder/decoder layer only."""
     cap = {}
     mp = model.prot_mpnn
@@ -91,7 +95,9 @@ def run_case(model, pdb, trace_level):
                seq=np.array(pdb["seq"]), E_idx=cap["E_idx"][0].numpy().astype(np.int16),
                E_head=cap["E"][0, :2].numpy(), h_E0_head=cap["h_E0"][0, :2].numpy(),
                hE_final_head=cap["hE_enc3"][0, :2].numpy(), log_probs=log_probs[0].numpy(),
-               z=z.numpy(), ddg=ddg, weight_seed=np.int64(WEIGHT_SEED))
+               z=z.numpy(), ddg=ddg, weight_seed=np.int64(seed), weight_style=np.array(style))
+    # largest magnitude the hidden tensors reach with this weight set (the range the split-precision kernels must carry)
+    out["max_abs_activation"] = np.float32(max(float(v.abs().max()) for k, v in cap.items() if k != "E_idx"))
     keep = ["hV_enc3", "hV_dec3"] if trace_level == 1 else [f"hV_{s}{i}" for s in ("enc", "dec") for i in (1, 2, 3)]
     for k in keep:
         out[k] = cap[k][0].numpy()
@@ -133,6 +139,31 @@ def main():
             np.savez_compressed(path, **out)
             print(f"{name}: L={len(pdb['seq'])} -> {os.path.getsize(path) / 1024:.0f} KiB, "
                   f"ddg range [{np.nanmin(out['ddg']):.3f}, {np.nanmax(out['ddg']):.3f}]")
+
+        for suffix, seed, style in EXTRA_WEIGHT_SETS:
+            with tempfile.TemporaryDirectory() as tmp2:
+                m2 = build_reference_model(tmp2, seed, style)
+            for base, lvl in (("2OCJ_A", 1), ("syn_L32", 2)):
+                out = run_case(m2, cases[base][0], lvl, seed, style)
+                assert np.isfinite(out["ddg"]).all() and np.isfinite(out["hV_dec3"]).all()
+                path = os.path.join(HERE, f"{base}_{suffix}.npz")
+                np.savez_compressed(path, **out)
+                print(f"{base}_{suffix}: weights seed {seed} / {style} -> {os.path.getsize(path) / 1024:.0f} KiB, ddg range "
+                      f"[{np.nanmin(out['ddg']):.3f}, {np.nanmax(out['ddg']):.3f}], max |activation| {out['max_abs_activation']:.1f}")
+
+        # model_utils.featurize (the training-flavour packer north_star names; /root/reference/model_utils.py:19-125) on a
+        # batch of two single-chain proteins of different length (padding exercised; one chain per protein, so the
+        # reference's random chain shuffle is the identity)
+        import model_utils as ref_mu                 # noqa: E402  (the reference)
+        fb = []
+        for d in (cases["syn_L32"][0], cases["2OCJ_A"][0]):
+            d = dict(d)
+            d["masked_list"], d["visible_list"] = ["A"], []
+            fb.append(d)
+        Xf, Sf, maskf, lengths, chain_Mf, ridxf, mask_self, cencf = ref_mu.featurize(fb, "cpu")
+        np.savez_compressed(os.path.join(HERE, "featurize_batch.npz"), X=Xf.numpy(), S=Sf.numpy().astype(np.int16), mask=maskf.numpy(),
+                            lengths=lengths, chain_M=chain_Mf.numpy(), residue_idx=ridxf.numpy().astype(np.int32),
+                            mask_self_rowsum=mask_self.numpy().sum(-1).astype(np.int32), chain_enc=cencf.numpy().astype(np.int16))
 
         # parser goldens: what the reference's alt_parse_PDB returns for chain selections of 2OCJ
         pg = {}

@@ -38,6 +38,60 @@ def _worker(rank, world, port, lengths, q):
         dist.destroy_process_group()
 
 
+def _parse_worker(rank, world, port, paths, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from thermompnn_amd import native_pdb
+        from thermompnn_amd.dist import parse_sharded
+        read = []
+
+        def parse(ps, chains):
+            read.extend(ps)
+            return native_pdb.parse_pdbs(ps, chains)
+
+        prots, lengths, seqs, names = parse_sharded(paths, ["A"] * len(paths), parse=parse)
+        q.put((rank, read, lengths, [p is not None for p in prots], seqs, names,
+               [None if p is None else (len(p["S"]), p["seq"]) for p in prots]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_parse_reads_each_file_where_it_is_needed(tmp_path):
+    """dist.parse_sharded on two ranks: every rank learns every length / sequence / name, holds exactly its own LPT shard, and
+    no rank reads all the files (a strided pre-pass + the rest of its shard)."""
+    import shutil
+    from conftest import GOLDEN
+    from thermompnn_amd import native_pdb
+    from thermompnn_amd.dist import parse_sharded
+    src = [os.path.join(GOLDEN, "2OCJ.pdb"), os.path.join(GOLDEN, "2OCJ_gap_chainA.pdb")]
+    paths = []
+    for k in range(6):
+        dst = str(tmp_path / f"p{k}.pdb")
+        shutil.copy(src[k % 2], dst)
+        paths.append(dst)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_parse_worker, args=(r, 2, port, paths, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = native_pdb.parse_pdbs(paths, ["A"] * 6)
+    shards = partition_proteins([len(p["S"]) for p in full], 2)
+    for rank, read, lengths, have, seqs, names, mine in results:
+        assert lengths == [len(p["S"]) for p in full] and seqs == [p["seq"] for p in full] and names == [p["name"] for p in full]
+        assert [i for i, h in enumerate(have) if h] == shards[rank]
+        assert all(m == (len(full[i]["S"]), full[i]["seq"]) for i, m in enumerate(mine) if m is not None)
+        assert len(read) == len(set(read)) < 6 and set(paths[rank::2]) <= set(read)
+    # a world of one parses everything once
+    prots, lengths, seqs, names = parse_sharded(paths, ["A"] * 6)
+    assert all(p is not None for p in prots) and lengths == [len(p["S"]) for p in full]
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -6,13 +6,51 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, load_golden, tol_scale, weights_for_case
 
 pytestmark = pytest.mark.gpu
 
 TOL_INTERMEDIATE = 1e-5   # abs; SURVEY §8c
 TOL_DDG = 1e-4            # kcal/mol; BASELINE.json north_star
 CASES = ["2OCJ_A", "2OCJ_A_gap", "2OCJ_AB", "syn_L32", "syn_L256", "syn_L256_s1"]
+# the same proteins through two more weight sets of the imported reference (make_golden.EXTRA_WEIGHT_SETS): a second Xavier draw
+# and the heavy "hot" draw (matrices x 3, biases x 5, LayerNorm gamma in [-2, 2]; tolerances scale with the tensors, conftest.tol_scale)
+EXTRA_CASES = ["2OCJ_A_w1", "syn_L32_w1", "2OCJ_A_hot", "syn_L32_hot"]
+_ENGINES = {}
+WORST = {}          # (precision, quantity) -> worst |hip - reference| / tolerance seen in this session (written to gpurun_out/)
+
+
+def engine_for(g, precision=None):
+    """One engine per (weight set, precision) of the golden fixtures."""
+    from thermompnn_amd.engine import Engine
+    key = (int(g["weight_seed"]), str(g["weight_style"]) if "weight_style" in g else "xavier", precision)
+    if key not in _ENGINES:
+        _ENGINES[key] = Engine(weights_for_case(g), "cuda:0", 48, precision=precision)
+    return _ENGINES[key]
+
+
+def close(got, want, tol, g, what, prec):
+    """assert_allclose with the tolerance scaled for the hot draw; records the worst error / tolerance ratio."""
+    atol = tol * tol_scale(g, want)
+    err = float(np.nanmax(np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64)))) if np.size(want) else 0.0
+    style = str(g["weight_style"]) if "weight_style" in g else "xavier"
+    k = f"{prec}/{style}/{what}"
+    if err / atol > WORST.get(k, {"ratio": -1})["ratio"]:
+        WORST[k] = {"ratio": err / atol, "abs_err": err, "atol": atol}
+    np.testing.assert_allclose(got, want, atol=atol, rtol=0, err_msg=what)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_worst():
+    yield
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(GOLDEN)), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_worst_errors.json"), "w") as fh:
+            json.dump(WORST, fh, indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 @pytest.fixture(scope="module")
@@ -85,9 +123,26 @@ def test_library_is_the_hip_build():
         assert "libtmpnn.so" in fh.read()
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_stagewise_parity_vs_oracle(case, engine, synthetic_weights):
+@pytest.mark.parametrize("case", CASES + EXTRA_CASES)
+def test_stagewise_parity_vs_oracle(case):
     g = load_golden(case)
+    check_stagewise(g, engine_for(g), weights_for_case(g))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "f16x2"])
+def test_extra_weight_sets_in_every_precision(mode):
+    """Second Xavier draw + the hot draw, stage by stage and fused, on every matrix-core path (the accuracy margin of the
+    split-precision kernels at larger activations; the worst error / tolerance per precision lands in
+    gpurun_out/parity_worst_errors.json and is quoted in DESIGN.md)."""
+    for case in EXTRA_CASES:
+        g = load_golden(case)
+        eng = engine_for(g, mode)
+        check_stagewise(g, eng, weights_for_case(g))
+        check_fused_forward(case, eng, weights_for_case(g))
+
+
+def check_stagewise(g, engine, synthetic_weights):
+    prec = engine.precision
     p = packed_inputs(g)
     L, valid = p["L"], np.nonzero(g["mask"] > 0)[0]
     Keff = min(48, L)
@@ -108,39 +163,40 @@ def test_stagewise_parity_vs_oracle(case, engine, synthetic_weights):
     # K1: featurizer output E (LayerNorm) and h_E = W_e E + b
     h_E, E = engine.edge_featurize(p["X"], p["ridx"], p["cenc"], E_idx, D_nb, want_E=True)
     a, b = align(E.cpu().numpy(), ei, tr["E"], tr["E_idx"], valid)
-    np.testing.assert_allclose(a, b, atol=TOL_INTERMEDIATE, rtol=0)
+    close(a, b, TOL_INTERMEDIATE, g, "E", prec)
     a, b = align(h_E.cpu().numpy(), ei, tr["h_E0"], tr["E_idx"], valid)
-    np.testing.assert_allclose(a, b, atol=TOL_INTERMEDIATE, rtol=0)
+    close(a, b, TOL_INTERMEDIATE, g, "h_E0", prec)
     assert (h_E.cpu().numpy()[:, Keff:] == 0).all()
 
     # K2/K3: encoder
     h_V = torch.zeros((L, 128), device="cuda:0")
     for l in range(3):
         engine.enc_layer(l, h_V, h_E, E_idx, p["mask"])
-        np.testing.assert_allclose(h_V.cpu().numpy(), tr[f"hV_enc{l + 1}"], atol=TOL_INTERMEDIATE, rtol=0, err_msg=f"enc{l}")
+        close(h_V.cpu().numpy(), tr[f"hV_enc{l + 1}"], TOL_INTERMEDIATE, g, f"hV_enc{l + 1}", prec)
     a, b = align(h_E.cpu().numpy(), ei, tr["h_E_final"], tr["E_idx"], valid)
-    np.testing.assert_allclose(a, b, atol=TOL_INTERMEDIATE, rtol=0)
+    close(a, b, TOL_INTERMEDIATE, g, "h_E_final", prec)
 
     # K4: decoder
     hs = []
     for l in range(3):
         h_V = engine.dec_layer(l, h_V, h_E, E_idx, p["S"], p["mask"])
         hs.append(h_V)
-        np.testing.assert_allclose(h_V.cpu().numpy(), tr[f"hV_dec{l + 1}"], atol=TOL_INTERMEDIATE, rtol=0, err_msg=f"dec{l}")
+        close(h_V.cpu().numpy(), tr[f"hV_dec{l + 1}"], TOL_INTERMEDIATE, g, f"hV_dec{l + 1}", prec)
     assert (hs[2].cpu().numpy()[g["mask"] == 0] == 0).all()
 
     # epilogues: W_s embedding, logits, head
     np.testing.assert_array_equal(engine.seq_embed(p["S"]).cpu().numpy(), tr["h_S"])
-    np.testing.assert_allclose(engine.log_probs(hs[2]).cpu().numpy(), tr["log_probs"], atol=TOL_INTERMEDIATE, rtol=0)
+    close(engine.log_probs(hs[2]).cpu().numpy(), tr["log_probs"], TOL_INTERMEDIATE, g, "log_probs", prec)
     ddg, z = engine.ddg_head(hs[2], hs[1], p["S"], want_z=True)
-    np.testing.assert_allclose(z.cpu().numpy(), tr["z"], atol=TOL_INTERMEDIATE, rtol=0)
-    np.testing.assert_allclose(ddg.cpu().numpy(), tr["ddg"], atol=TOL_DDG, rtol=0)
+    close(z.cpu().numpy(), tr["z"], TOL_INTERMEDIATE, g, "z", prec)
+    close(ddg.cpu().numpy(), tr["ddg"], TOL_DDG, g, "ddg", prec)
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_fused_forward_vs_reference_golden(case, engine, synthetic_weights):
+@pytest.mark.parametrize("case", CASES + EXTRA_CASES)
+def test_fused_forward_vs_reference_golden(case):
     """tmpnn_ssm_forward against the vectors the imported reference produced (tests/golden/make_golden.py)."""
-    check_fused_forward(case, engine, synthetic_weights)
+    g = load_golden(case)
+    check_fused_forward(case, engine_for(g), weights_for_case(g))
 
 
 def check_fused_forward(case, engine, synthetic_weights):
@@ -159,14 +215,15 @@ def check_fused_forward(case, engine, synthetic_weights):
         tr = oracle_trace(synthetic_weights, g, ei[:, :Keff])
         g = dict(g, hV_dec3=tr["hV_dec3"], log_probs=tr["log_probs"], ddg=tr["ddg"][:, :20])
     hid = res["hidden"].cpu().numpy()
-    np.testing.assert_allclose(hid[2], g["hV_dec3"], atol=TOL_INTERMEDIATE, rtol=0)
+    prec = engine.precision + "/fused"
+    close(hid[2], g["hV_dec3"], TOL_INTERMEDIATE, g, "hV_dec3", prec)
     if "hV_dec1" in g:
-        np.testing.assert_allclose(hid[0], g["hV_dec1"], atol=TOL_INTERMEDIATE, rtol=0)
-        np.testing.assert_allclose(hid[1], g["hV_dec2"], atol=TOL_INTERMEDIATE, rtol=0)
-    np.testing.assert_allclose(res["log_probs"].cpu().numpy(), g["log_probs"], atol=TOL_INTERMEDIATE, rtol=0)
+        close(hid[0], g["hV_dec1"], TOL_INTERMEDIATE, g, "hV_dec1", prec)
+        close(hid[1], g["hV_dec2"], TOL_INTERMEDIATE, g, "hV_dec2", prec)
+    close(res["log_probs"].cpu().numpy(), g["log_probs"], TOL_INTERMEDIATE, g, "log_probs", prec)
     ddg = res["ddg"].cpu().numpy()
     have = ~np.isnan(g["ddg"][:, 0])
-    np.testing.assert_allclose(ddg[have][:, :20], g["ddg"][have], atol=TOL_DDG, rtol=0)
+    close(ddg[have][:, :20], g["ddg"][have], TOL_DDG, g, "ddg", prec)
     wt = g["S"].astype(np.int64)
     assert (ddg[np.arange(len(wt)), wt] == 0).all()                       # wt -> wt rows are exactly 0
 
@@ -341,18 +398,29 @@ def test_full_size_properties(engine):
         assert np.percentile(diff, 95) < 1e-3 and diff.max() < 0.1
 
 
-def test_large_chain_vs_oracle(engine, synthetic_weights):
+@pytest.mark.parametrize("L,seed", [(1024, 7), (2048, 3)], ids=["L1024", "config5_L2048"])
+def test_large_chain_vs_oracle(L, seed, engine, synthetic_weights):
+    """One long chain against the CPU oracle over the WHOLE table — L = 2048 / seed 3 is BASELINE.json configs[4] at full size
+    (the rows > 512 path of the k-NN kernel, 98 304 edges); decoder states compared too."""
     from oracle import thermompnn_oracle as orc
     from thermompnn_amd.synthetic import synthetic_backbone
-    L = 1024
-    Xn, seq = synthetic_backbone(L, 7)
+    Xn, seq = synthetic_backbone(L, seed)
     X = torch.tensor(Xn, dtype=torch.float32)
     S = torch.tensor(["ACDEFGHIKLMNPQRSTVWY".index(c) for c in seq])
     ones, ar = torch.ones(1, L), torch.arange(L)[None]
-    with torch.no_grad():
-        want = orc.ssm_table(synthetic_weights, X[None], S[None], ones, ones, ar, ones.long(), 48)[0].numpy()
-    r = engine.ssm_forward(X, S.int(), torch.ones(L), torch.arange(L), torch.ones(L), torch.tensor([0, L], dtype=torch.int32))
+    r = engine.ssm_forward(X, S.int(), torch.ones(L), torch.arange(L), torch.ones(L), torch.tensor([0, L], dtype=torch.int32),
+                           want_hidden=True, want_E_idx=True)
+    tr = {}
+    with torch.no_grad():    # on the engine's graph: an exact K-th-distance tie (implementation-defined in torch.topk) cannot leak in
+        want = orc.ssm_table(synthetic_weights, X[None], S[None], ones, ones, ar, ones.long(), 48, trace=tr,
+                             E_idx_override=r["E_idx"].cpu().long()[None])[0].numpy()
+        free = {}
+        orc.ssm_table(synthetic_weights, X[None], S[None], ones, ones, ar, ones.long(), 48, trace=free) if L <= 1024 else None
     np.testing.assert_allclose(r["ddg"].cpu().numpy(), want, atol=TOL_DDG, rtol=0)
+    np.testing.assert_allclose(r["hidden"][2].cpu().numpy(), tr["hV_dec3"][0].numpy(), atol=TOL_INTERMEDIATE, rtol=0)
+    if free:                 # and the graph itself: same neighbour sets as the oracle's own top-k, ties aside
+        a, b = np.sort(r["E_idx"].cpu().numpy(), 1), np.sort(free["E_idx"][0].numpy(), 1)
+        assert (a == b).all(1).mean() > 0.995
 
 
 def test_custom_inference_script_end_to_end(tmp_path):
@@ -683,11 +751,18 @@ def test_config4_listed_mutations(engine, synthetic_weights):
         select_mutations(tables, np.array([[0, 9999, 0]]))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _torchrun(args, env, timeout=900):
     import subprocess
     import sys
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29571"] + args
+           "--master-port", str(_free_port())] + args
     return subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
 
 
@@ -729,6 +804,7 @@ def test_two_rank_bench_and_cli(tmp_path):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["preds_per_step"] == 2 * 2 * 256 * 20
+    assert d["collective"]["ranks_seen"] == 2 and d["collective"]["world_size"] == 2
     from thermompnn_amd import ssm_scan
     pdbs = [os.path.join(GOLDEN, "2OCJ.pdb"), os.path.join(GOLDEN, "2OCJ_gap_chainA.pdb")]
     single = ssm_scan.main(pdbs + ["--synthetic_weights", "0", "--centrality", "--out", str(tmp_path / "one.csv")])
@@ -745,6 +821,78 @@ def test_two_rank_bench_and_cli(tmp_path):
     full = {(r_["pdb"], r_["position"], r_["mutation"]): r_["ddG_pred"] for r_ in csv.DictReader(open(single))}
     assert [(r_["pdb"], r_["position"], r_["mutation"]) for r_ in rows] == [("2OCJ", "5", "W"), ("2OCJ_gap_chainA", "17", "A"), ("2OCJ", "5", "A")]
     assert all(full[(r_["pdb"], r_["position"], r_["mutation"])] == r_["ddG_pred"] for r_ in rows)
+
+
+def _bench(args, env=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, env=dict(os.environ, **(env or {})),
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_and_proves_its_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the contract command) starts itself under
+    torch.distributed.run and echoes what the process group saw: world size, all_reduce(ones), one identity per rank."""
+    smoke = {"TMPNN_BENCH_ONE_DEVICE": "1", "TMPNN_BENCH_BACKEND": "gloo", "TMPNN_BENCH_WATCHDOG": "300"}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    os_env_backup = dict(os.environ)
+    try:
+        os.environ.clear()
+        os.environ.update(env)
+        d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--proteins-per-gpu", "2"], smoke)
+    finally:
+        os.environ.clear()
+        os.environ.update(os_env_backup)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["preds_per_step"] == 2 * 2 * 256 * 20
+    c = d["collective"]
+    assert c["world_size"] == 2 and c["ranks_seen"] == 2 and len(c["devices"]) == 2 and c["backend"].startswith("gloo")
+    assert sorted(x["rank"] for x in c["devices"]) == [0, 1] and c["one_device_smoke_mode"] is True
+    sp = d["ms_per_step_spread"]
+    assert sp["n"] == 2 and sp["min"] <= sp["median"] <= sp["max"]
+
+
+def test_bench_strong_scaling_mode_is_rank_invariant():
+    """--scaling strong = BASELINE configs[3] (300 proteins / 200 000 listed mutants, fixed total work). The listed values
+    gathered from two ranks are the same numbers as from one (their float64 sum is bit-equal)."""
+    one = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--scaling", "strong"])
+    two = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--scaling", "strong"],
+                 {"TMPNN_BENCH_ONE_DEVICE": "1", "TMPNN_BENCH_BACKEND": "gloo", "TMPNN_BENCH_WATCHDOG": "300"})
+    for d, n in ((one, 1), (two, 2)):
+        assert d["scaling"] == "strong" and d["n_gpus"] == n and d["config"]["preds_per_step"] == 200000
+        assert abs(d["value"] - 200000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    assert one["checksum_listed"] == two["checksum_listed"] and np.isfinite(one["checksum_listed"])
+    assert two["collective"]["ranks_seen"] == 2 and two["excl_collective"]["value"] > 0
+
+
+def test_captured_graph_owns_its_buffers(synthetic_weights):
+    """A graph captured on a small protein keeps replaying correctly after the engine's shared workspace has been
+    reallocated by a larger forward and by a larger capture (the captured launches used to point into it)."""
+    small, big = packed_inputs(load_golden("syn_L32")), packed_inputs(load_golden("syn_L256"))
+    args = lambda p: (p["X"], p["S"], p["mask"], p["ridx"], p["cenc"], p["offsets"])
+    from thermompnn_amd.engine import Engine
+    want = Engine(synthetic_weights, "cuda:0", 48).ssm_forward(*args(small))["ddg"].clone()
+    eng = Engine(synthetic_weights, "cuda:0", 48)                               # an engine whose workspace does not exist yet
+    graph, out = eng.capture_graph(*args(small), max_len=small["L"])
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["ddg"], want)
+    big_ddg = eng.ssm_forward(*args(big))["ddg"].clone()                        # (re)allocates the engine's own workspace
+    g2, out2 = eng.capture_graph(*args(big), max_len=big["L"])                  # and a second, larger graph
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda:0") for _ in range(8)]   # recycle whatever was freed
+    del junk
+    out["ddg"].zero_()
+    graph.replay()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["ddg"], want) and torch.equal(out2["ddg"], big_ddg)
+    eng.check_graph_status(graph)
+    eng.check_graph_status(g2)
 
 
 def test_range_overflow_is_detected_and_retried(synthetic_weights):
@@ -849,4 +997,6 @@ def test_bench_contract_line():
     assert abs(d["value"] - 2 * 256 * 20 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["bound"] == ("hbm" if rf["t_hbm_roof_us"] >= rf["t_mfma_roof_us"] else "mfma")
+    assert 0 < d["pipeline"]["frac_of_binding_roof"] < 1 and d["ms_per_step_spread"]["n"] == 2
     assert d["roofline_gather"]["bound"] == "hbm" and d["roofline_gather"]["unit"] == "GB/s"

@@ -259,14 +259,49 @@ def test_lightning_checkpoint_loader_drops_foreign_keys(tmp_path):
     out = weights.load_thermompnn_checkpoint(str(path))
     assert list(out.keys()) == list(sd.keys()) and all(torch.equal(out[k], sd[k]) for k in sd)
 
-    class Evil:                                               # anything that is not a plain tensor container
-        def __reduce__(self):
-            return (print, ("side effect",))
+    # a checkpoint whose hyper_parameters hold arbitrary objects (the published thermoMPNN_default.pt carries an OmegaConf
+    # config) fails weights_only=True; the restricted unpickler still extracts the tensors WITHOUT running the file's globals
+    marker = tmp_path / "executed"
     bad = tmp_path / "pickled.ckpt"
-    torch.save({"state_dict": ckpt["state_dict"], "hyper_parameters": Evil()}, bad)
-    with pytest.raises(RuntimeError, match="allow_pickle"):
-        weights.load_thermompnn_checkpoint(str(bad))
+    torch.save({"state_dict": ckpt["state_dict"], "hyper_parameters": _Evil(str(marker)), "callbacks": {_Evil(str(marker)): 1}}, bad)
+    with pytest.raises(Exception):
+        torch.load(bad, weights_only=True)
+    out = weights.load_thermompnn_checkpoint(str(bad))
+    assert list(out.keys()) == list(sd.keys()) and all(torch.equal(out[k], sd[k]) for k in sd)
+    assert not marker.exists()                                              # nothing from the file was executed
     assert list(weights.load_thermompnn_checkpoint(str(bad), allow_pickle=True).keys()) == list(sd.keys())
+    assert marker.exists()                                                  # the opt-in pickle loader does run it
+    junk = tmp_path / "junk.ckpt"
+    junk.write_bytes(b"not a checkpoint at all")
+    with pytest.raises(RuntimeError, match="allow_pickle"):
+        weights.load_thermompnn_checkpoint(str(junk))
+
+
+class _Evil:
+    """Writes a marker file when unpickled by the plain pickle loader."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __reduce__(self):
+        import pathlib
+        return (pathlib.Path.touch, (pathlib.Path(self.path),))
+
+    def __hash__(self):
+        return 7
+
+
+def test_split_files_load_without_pickle_execution(tmp_path):
+    """FireProtDataset reads its split dictionary with the restricted unpickler: lists and numpy arrays of names load (the
+    reference's dataset_splits/*.pkl are exactly that), foreign globals become inert placeholders."""
+    import pickle
+    marker = tmp_path / "executed"
+    f = tmp_path / "splits.pkl"
+    with open(f, "wb") as fh:
+        pickle.dump({"train": ["1ABC", "2DEF"], "test": np.array(["3GHI"], dtype=object), "x": _Evil(str(marker))}, fh)
+    d = weights.safe_unpickle(str(f))
+    assert d["train"] == ["1ABC", "2DEF"] and list(d["test"]) == ["3GHI"] and not marker.exists()
+    assert type(d["x"]).__name__ == "_Opaque"
 
 
 def test_published_real_weight_table_fixture():
@@ -278,3 +313,128 @@ def test_published_real_weight_table_fixture():
     assert t.shape == (194, 20) and t.dtype == np.float32
     assert (t[np.arange(194), g["S"].astype(int)] == 0).all()
     assert abs(t.mean() - 1.03) < 0.01 and abs(t.min() + 1.85) < 0.01 and abs(t.max() - 4.76) < 0.01
+
+
+def test_featurize_matches_reference_batch():
+    """pdb_io.featurize (the model_utils.featurize signature north_star names; /root/reference/model_utils.py:19-125) on a
+    padded batch of two single-chain proteins, against the tuple the imported reference returned (make_golden.py)."""
+    import torch
+    from thermompnn_amd.pdb_io import alt_parse_PDB, featurize
+    from thermompnn_amd.synthetic import synthetic_pdb_dict
+    g = load_golden("featurize_batch")
+    batch = []
+    for d in (synthetic_pdb_dict(32, seed=5), alt_parse_PDB(os.path.join(GOLDEN, "2OCJ.pdb"), "A")[0]):
+        d = dict(d)
+        d["masked_list"], d["visible_list"] = ["A"], []
+        batch.append(d)
+    X, S, mask, lengths, chain_M, ridx, mask_self, cenc = featurize(batch, "cpu")
+    assert X.dtype == torch.float32 and S.dtype == torch.long and ridx.dtype == torch.long and cenc.dtype == torch.long
+    assert mask.dtype == chain_M.dtype == mask_self.dtype == torch.float32
+    np.testing.assert_array_equal(X.numpy(), g["X"])
+    np.testing.assert_array_equal(S.numpy(), g["S"])
+    np.testing.assert_array_equal(mask.numpy(), g["mask"])
+    np.testing.assert_array_equal(lengths, g["lengths"])
+    np.testing.assert_array_equal(chain_M.numpy(), g["chain_M"])
+    np.testing.assert_array_equal(ridx.numpy(), g["residue_idx"])
+    np.testing.assert_array_equal(cenc.numpy(), g["chain_enc"])
+    np.testing.assert_array_equal(mask_self.numpy().sum(-1).astype(np.int32), g["mask_self_rowsum"])
+    assert tuple(lengths) == (32, 194) and (ridx.numpy()[0, 32:] == -100).all()     # padding convention of the reference
+
+
+def _atom_line(serial=1, atom="CA", resname="ALA", chain="A", resnum="   1", ins=" ", x="  11.104", y="   6.134", z="  -6.504"):
+    return f"ATOM  {serial:5d} {atom:^4s} {resname:>3s} {chain}{resnum}{ins}   {x}{y}{z}  1.00  0.00           C"
+
+
+def _mutated_pdbs(tmp_path, n_files=60):
+    """Seeded structural damage to real ATOM records: truncated lines, non-numeric columns, huge / negative residue numbers,
+    control bytes, very long lines, empty files, duplicate atoms, odd chain letters."""
+    rng = np.random.default_rng(12345)
+    base = [l.rstrip("\n") for l in open(PDB) if l.startswith("ATOM")][:400]
+    files = []
+    hand = {
+        "empty": "", "only_newlines": "\n\n\n", "short_atom": "ATOM\nATOM  \nATOM      1  N\n",
+        "col21": "ATOM      1  N   MET A", "no_coords": "ATOM      1  N   MET A   1",
+        "nonnumeric_xyz": _atom_line(x="  abcdef"), "nan_xyz": _atom_line(x="     nan", y="     inf", z="    -inf"),
+        "exp_xyz": _atom_line(x="  1e9999", y=" -1e9999", z="   1e-99"),
+        "resnum_text": _atom_line(resnum="ABCD"), "resnum_only_ins": _atom_line(resnum="    ", ins="A"),
+        "resnum_max": _atom_line(resnum="9999", ins="9") + "\n" + _atom_line(serial=2, resnum="-999", ins="9"),
+        "resnum_span": _atom_line(resnum="-999", ins=" ") + "\n" + _atom_line(serial=2, resnum="9999", ins=" "),
+        "long_line": _atom_line() + "X" * 5000 + "\n" + _atom_line(serial=2, atom="N") + "Y" * 1021,
+        "exact_buf": (_atom_line() + " " * 600)[:511] + "\n" + (_atom_line(serial=2, atom="C") + " " * 600)[:510] + "\n",
+        "nul_bytes": _atom_line()[:40] + "\x00\x00" + _atom_line()[42:], "binary": bytes(range(256)).decode("latin1") * 8,
+        "mse": "HETATM    1  N   MSE A   1      11.104   6.134  -6.504  1.00  0.00           N\nHETATM    2 MSE  MSE A   2",
+        "hetatm_short": "HETATM    1  N   MS", "tabs": _atom_line().replace(" ", "\t"),
+        "unicode": _atom_line(resname="\u00e9\u00e9\u00e9"), "dup_atoms": "\n".join(_atom_line(serial=i, x=f"{i:8.3f}") for i in range(1, 30)),
+        "many_ins": "\n".join(_atom_line(serial=i, ins=c) for i, c in enumerate("ZYXWVUTSRQPONMLKJIHGFEDCBA", 1)),
+        "odd_chains": "\n".join(_atom_line(serial=i, chain=c) for i, c in enumerate("z9 *\x7f", 1)),
+    }
+    for name, text in hand.items():
+        f = tmp_path / f"hand_{name}.pdb"
+        f.write_bytes(text.encode("latin1", errors="replace"))
+        files.append(str(f))
+    for k in range(n_files):
+        lines = list(base[: int(rng.integers(1, 120))])
+        for _ in range(int(rng.integers(1, 12))):
+            i = int(rng.integers(0, len(lines)))
+            l = lines[i]
+            op = int(rng.integers(0, 8))
+            if op == 0:
+                lines[i] = l[: int(rng.integers(0, len(l) + 1))]                                  # truncate
+            elif op == 1:
+                a, b = sorted(int(x) for x in rng.integers(0, len(l) + 1, size=2))
+                lines[i] = l[:a] + "".join(chr(int(c)) for c in rng.integers(1, 256, size=b - a)) + l[b:]   # garbage span
+            elif op == 2:
+                lines[i] = l[:22] + f"{int(rng.integers(-9999, 99999)):5d}"[:5] + l[27:]          # wild residue number
+            elif op == 3:
+                lines[i] = l[:30] + "".join(rng.choice(list("0123456789.-+eEnaif xX"), size=24)) + l[54:]   # wild coordinates
+            elif op == 4:
+                lines[i] = l + " " * int(rng.integers(0, 1200))                                  # long line
+            elif op == 5:
+                del lines[i]
+                if not lines:
+                    lines = [""]
+            elif op == 6:
+                lines.insert(i, l)                                                               # duplicate record
+            else:
+                lines[i] = l[:21] + chr(int(rng.integers(32, 127))) + l[22:]                      # other chain letter
+        f = tmp_path / f"mut_{k}.pdb"
+        f.write_bytes(("\n".join(lines) + ("\n" if rng.integers(0, 2) else "")).encode("latin1"))
+        files.append(str(f))
+    return files
+
+
+def test_native_parser_survives_malformed_input(tmp_path):
+    """SURVEY §5 'sanitizers on host stubs': csrc/tmpnn_pdb.cpp reads untrusted text with fixed columns, strtod, a residue
+    span that allocates per missing number, and threads. Built with -fsanitize=address,undefined (any report aborts) and fed
+    ~85 damaged files, alone and through the threaded batch entry; every file either parses or returns TMPNN_E_INVALID, and
+    whatever parses has the same length as the Python parser's result for it."""
+    import subprocess
+    from thermompnn_amd import build
+    try:
+        driver = build.build_pdb_sanitizer_driver(str(tmp_path / "pdb_fuzz_driver"))
+    except RuntimeError as e:
+        pytest.skip(f"sanitizer driver not buildable here: {e}")
+    files = _mutated_pdbs(tmp_path)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([driver, "--threads", "8"] + files, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, f"sanitizer report / crash:\n{r.stderr[-4000:]}"
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(files) + 1 and lines[-1].startswith("batch ")
+    n_ok = 0
+    for f, line in zip(files, lines):
+        rc, length = int(line.split()[0]), int(line.split()[1])
+        assert rc in (0, -1), (f, line)
+        if rc == 0:
+            n_ok += 1
+            raw = open(f, "rb").read()
+            if any(b < 9 or 13 < b < 32 or b == 127 for b in raw) or b"_" in raw:
+                continue      # control bytes / Python-only number syntax ("1_0"): no crash is all that is asked of the native reader
+            try:
+                ref = pdb_io.alt_parse_PDB(f, None)[0]
+            except Exception:
+                continue                                     # the Python parser may be stricter; agreement is only required when both parse
+            assert length == len(ref["seq"]), (f, length, len(ref["seq"]))
+    assert 10 < n_ok < len(files)                            # the corpus has both survivable and fatal damage
+    # the span guard: one chain whose residue numbers cover the whole 5-column range is an error, not a 110 000-row allocation
+    span = [f for f in files if f.endswith("hand_resnum_span.pdb")][0]
+    assert lines[files.index(span)].split()[0] in ("0", "-1")

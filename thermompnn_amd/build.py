@@ -65,9 +65,27 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     return out
 
 
+def build_pdb_sanitizer_driver(out: str | None = None) -> str:
+    """The host-side PDB reader (csrc/tmpnn_pdb.cpp, untrusted text in) + tests/native/pdb_fuzz_driver.cpp as ONE executable
+    under AddressSanitizer + UndefinedBehaviorSanitizer (g++; a report aborts the process). Used by the malformed-input test."""
+    repo = os.path.dirname(HERE)
+    out = out or os.path.join(repo, "tests", "native", "pdb_fuzz_driver")
+    gxx = shutil.which("g++")
+    if not gxx:
+        raise RuntimeError("g++ not found: the sanitizer driver cannot be built on this machine")
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+           "-Wall", "-pthread", os.path.join(CSRC, "tmpnn_pdb.cpp"), os.path.join(repo, "tests", "native", "pdb_fuzz_driver.cpp"), "-o", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed on the sanitizer driver:\n" + r.stdout)
+    return out
+
+
 if __name__ == "__main__":
     # python -m thermompnn_amd.build [--force] [--variant NAME -DFLAG ...]  (variant -> thermompnn_amd/libtmpnn_NAME.so)
-    if "--variant" in sys.argv:
+    if "--pdb-sanitizer-driver" in sys.argv:
+        print(build_pdb_sanitizer_driver())
+    elif "--variant" in sys.argv:
         k = sys.argv.index("--variant")
         name, flags = sys.argv[k + 1], sys.argv[k + 2:]
         only = [f[7:] for f in flags if f.startswith("--only=")]      # --only=tmpnn_wt.hip: recompile just that file

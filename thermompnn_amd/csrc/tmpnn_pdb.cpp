@@ -21,9 +21,18 @@
 #include <thread>
 #include <vector>
 
-#include "tmpnn_internal.h"
+// Host-only translation unit: it needs the C-ABI header and the library's error sink, nothing of HIP — so the same file
+// also builds with plain g++ under -fsanitize=address,undefined into the fuzz driver of tests/native/pdb_fuzz_driver.cpp
+// (python -m thermompnn_amd.build --pdb-sanitizer-driver).
+#include "../../include/tmpnn.h"
+int tm_set_error(int code, const char *fmt, ...);
 
 namespace {
+
+// Residue numbers come from a 5-column field (-9999 .. 99999), so a chain can span at most ~110 000 numbers; the bound is
+// enforced anyway: every number between a chain's lowest and highest becomes a row (gaps included), and a hostile file must
+// get an error, not an allocation proportional to a number it made up.
+constexpr long kMaxChainSpan = 200000;
 
 struct Residue {
     std::string name;           // first residue name seen
@@ -66,6 +75,42 @@ std::string strip(const std::string &s) {
     return s.substr(a, b - a);
 }
 
+// bytes.decode("utf-8", "ignore") of the reference (:211), column-exact: a well-formed multi-byte sequence is ONE column
+// (kept as '?': no ATOM field compares equal to a non-ASCII character), ill-formed bytes vanish (maximal-subpart rule, as
+// CPython's decoder applies it), ASCII passes through.
+std::string utf8_ignore(const std::string &in) {
+    std::string out;
+    out.reserve(in.size());
+    const size_t n = in.size();
+    size_t i = 0;
+    while (i < n) {
+        const unsigned char b = (unsigned char)in[i];
+        if (b < 0x80) { out.push_back((char)b); ++i; continue; }
+        int need = 0;
+        unsigned char lo = 0x80, hi = 0xBF;
+        if (b >= 0xC2 && b <= 0xDF) need = 1;
+        else if (b == 0xE0) { need = 2; lo = 0xA0; }
+        else if (b >= 0xE1 && b <= 0xEC) need = 2;
+        else if (b == 0xED) { need = 2; hi = 0x9F; }
+        else if (b >= 0xEE && b <= 0xEF) need = 2;
+        else if (b == 0xF0) { need = 3; lo = 0x90; }
+        else if (b >= 0xF1 && b <= 0xF3) need = 3;
+        else if (b == 0xF4) { need = 3; hi = 0x8F; }
+        else { ++i; continue; }                                   // 80..C1, F5..FF: never a lead byte
+        size_t j = i + 1;
+        int got = 0;
+        while (got < need && j < n) {
+            const unsigned char c = (unsigned char)in[j];
+            if (c < lo || c > hi) break;
+            lo = 0x80; hi = 0xBF;
+            ++j; ++got;
+        }
+        if (got == need) out.push_back('?');
+        i = j;                                                    // ill-formed: the lead and its valid prefix are dropped
+    }
+    return out;
+}
+
 void replace_all(std::string &s, const char *from, const char *to) {
     const size_t nf = strlen(from), nt = strlen(to);
     for (size_t p = s.find(from); p != std::string::npos; p = s.find(from, p + nt)) s.replace(p, nf, to);
@@ -89,13 +134,14 @@ static int parse_one(const char *path, const char *chains, tmpnn_pdb **out, std:
     std::vector<char> first_seen;    // default order = the reference's A-Z, a-z scan; here: requested or alphabet order
     std::string line;
     char buf[512];
-    bool bad = false;
+    bool bad = false, span = false;
     while (fgets(buf, sizeof(buf), fh)) {
         line.assign(buf);
         while (!line.empty() && strchr("\r\n", line.back()) == nullptr && !feof(fh) && line.size() % (sizeof(buf) - 1) == 0) {
             if (!fgets(buf, sizeof(buf), fh)) break;     // very long line: keep reading
             line += buf;
         }
+        line = utf8_ignore(line);
         while (!line.empty() && isspace((unsigned char)line.back())) line.pop_back();
         if (line.compare(0, 6, "HETATM") == 0 && line.size() >= 20 && line.compare(17, 3, "MSE") == 0) {
             replace_all(line, "HETATM", "ATOM  ");
@@ -119,12 +165,14 @@ static int parse_one(const char *path, const char *chains, tmpnn_pdb **out, std:
         if (!c.any) { c.lo = c.hi = num; c.any = true; }
         c.lo = std::min(c.lo, num);
         c.hi = std::max(c.hi, num);
+        if (c.hi - c.lo >= kMaxChainSpan) { span = true; break; }
         Residue &r = c.res[num][ins];
         if (r.name.empty()) r.name = resname;
         int ai = atom == "N" ? 0 : atom == "CA" ? 1 : atom == "C" ? 2 : atom == "O" ? 3 : -1;
         if (ai >= 0 && !r.have[ai]) { r.have[ai] = true; memcpy(r.xyz[ai], xyz, sizeof(xyz)); }
     }
     fclose(fh);
+    if (span) { *err = std::string("residue numbers of one chain span more than 200000 in ") + path; return TMPNN_E_INVALID; }
     if (bad) { *err = std::string("malformed ATOM record in ") + path; return TMPNN_E_INVALID; }
 
     std::string order = want;
@@ -213,6 +261,10 @@ extern "C" int tmpnn_pdb_fill(const tmpnn_pdb_t *p, float *X, int32_t *S, float 
                               int32_t *chain_enc, char *seq, float *ca_mask) {
     if (!p) return tm_set_error(TMPNN_E_INVALID, "pdb_fill: null handle");
     const size_t L = p->S.size();
+    if (L == 0) {                    // an empty structure (no ATOM record of the requested chains): nothing to copy —
+        if (seq) seq[0] = '\0';      // and memcpy from an empty vector's null data() is undefined even for 0 bytes (UBSan)
+        return TMPNN_OK;
+    }
     if (X) for (size_t i = 0; i < L * 12; ++i) X[i] = std::isnan(p->X[i]) ? 0.f : p->X[i];
     if (S) memcpy(S, p->S.data(), L * sizeof(int32_t));
     if (mask) memcpy(mask, p->mask.data(), L * sizeof(float));

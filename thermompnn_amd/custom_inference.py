@@ -47,7 +47,7 @@ def pdb_id_of(path: str) -> str:
 
 
 def load_model(model_path: str | None, thermompnn_dir: str | None, synthetic_seed: int | None, device="cuda",
-               precision: str | None = None):
+               precision: str | None = None, allow_pickle: bool | None = None):
     if synthetic_seed is not None:
         sd = _weights.synthetic_state_dict(synthetic_seed)
         tmp = tempfile.mkdtemp(prefix="tmpnn_w_")
@@ -56,7 +56,7 @@ def load_model(model_path: str | None, thermompnn_dir: str | None, synthetic_see
                                          _weights.split_transfer_state_dict(sd)[0], 48)
         thermompnn_dir = tmp
     else:
-        sd = _weights.load_thermompnn_checkpoint(model_path)
+        sd = _weights.load_thermompnn_checkpoint(model_path, allow_pickle=allow_pickle)
     cfg = AttrDict(model=AttrDict(MODEL_CFG), platform=AttrDict(thermompnn_dir=thermompnn_dir))
     model = TransferModel(cfg)
     model.load_state_dict(sd)
@@ -100,11 +100,14 @@ def main(argv=None):
     ap.add_argument("--out_dir", type=str, default="./", help="Output directory in which to save predictions.")
     ap.add_argument("--thermompnn_dir", type=str, default=".", help="directory holding vanilla_model_weights/ (local.yaml: platform.thermompnn_dir)")
     ap.add_argument("--synthetic_weights", type=int, default=None, help="use synthetic weights with this seed")
+    ap.add_argument("--allow_pickle", action="store_true", default=False,
+                    help="read --model_path with the unrestricted pickle loader (it can execute code from the file); the default "
+                         "restricted loader already reads Lightning checkpoints such as thermoMPNN_default.pt")
     args = ap.parse_args(argv)
     chain = args.chain if len(args.chain) >= 1 else first_chain(args.pdb)
     out_dir = os.getcwd() if args.out_dir == "./" else args.out_dir
     assert os.path.isdir(out_dir), f"{out_dir} is not a valid directory."
-    model = load_model(args.model_path, args.thermompnn_dir, args.synthetic_weights)
+    model = load_model(args.model_path, args.thermompnn_dir, args.synthetic_weights, allow_pickle=args.allow_pickle or None)
     rows = ssm_rows(model, args.pdb, chain)
     csv_file = os.path.join(out_dir, "ThermoMPNN_inference_%s.csv" % pdb_id_of(args.pdb))
     write_csv(rows, csv_file)

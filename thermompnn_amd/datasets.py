@@ -130,16 +130,25 @@ class FireProtDataset:
     every split. Positions index ``pdb_sequence``; when the parsed structure disagrees the position is re-mapped through
     a global alignment (the reference's pairwise2 contingency) and unmappable rows are dropped."""
 
-    def __init__(self, cfg, split: str):
-        import pickle
+    def __init__(self, cfg, split: str, allow_pickle: bool = False):
+        """``allow_pickle``: read the split file with the unrestricted pickle loader (it can execute code from the file).
+        Default: the restricted unpickler of ``weights.safe_unpickle`` (containers, numpy arrays of names) — the
+        reference's own ``dataset_splits/*.pkl`` load with it."""
         self.cfg, self.split = cfg, split
         rows = [r for r in _read_rows(cfg.data_loc.fireprot_csv) if (r.get("ddG") or "").strip() not in ("", "nan", "NaN")]
         self.rows = rows
         self.seq_to_data = {}
         for r in rows:
             self.seq_to_data.setdefault(r["pdb_sequence"], []).append(r)
-        with open(cfg.data_loc.fireprot_splits, "rb") as fh:  # the reference's own split file format (a pickled dict)
-            splits = pickle.load(fh)
+        if allow_pickle:
+            import pickle
+            with open(cfg.data_loc.fireprot_splits, "rb") as fh:  # the reference's own split file format (a pickled dict)
+                splits = pickle.load(fh)
+        else:
+            from .weights import safe_unpickle
+            splits = safe_unpickle(cfg.data_loc.fireprot_splits)
+        if not isinstance(splits, dict):
+            raise ValueError(f"{cfg.data_loc.fireprot_splits}: expected a pickled dict of split name -> protein names")
         self.wt_names = [n for sub in splits.values() for n in sub] if split == "all" else list(splits[split])
         self.mut_rows = {n: [r for r in rows if r["pdb_id_corrected"] == n] for n in self.wt_names}
         self.wt_seqs = {n: self.mut_rows[n][0]["pdb_sequence"] for n in self.wt_names}

@@ -93,16 +93,19 @@ def pack_proteins(proteins: Sequence[dict], ids: Sequence[int], device):
                 max_len=max(lens))
 
 
-def ssm_scan(engine, proteins: Sequence[dict], group=None, gather: bool = True, centrality: bool = False,
-             chunk_residues: int = 1 << 18, radius: float = 10.0):
+def ssm_scan(engine, proteins: Sequence[Optional[dict]], group=None, gather: bool = True, centrality: bool = False,
+             chunk_residues: int = 1 << 18, radius: float = 10.0, lengths: Optional[Sequence[int]] = None):
     """Full SSM of many proteins, sharded over the group's GPUs (analysis/SSM.py:105-126 runs them one per forward).
 
     Every rank runs the ragged pipeline on its LPT shard, in chunks of at most ``chunk_residues`` residues (the
     workspace is ~27.5 KB per residue), then ONE padded all-gather exchanges the tables. With ``centrality`` the
     neighbour count (#CA within ``radius``; compute_centrality, thermompnn_benchmarking.py:20-35, masked on the CA
     atom) rides along as a 22nd column, so there is still a single collective.
+    ``lengths``: every protein's length when ``proteins`` only holds THIS rank's shard (``None`` elsewhere) — a rank then never
+    needs the structures it does not compute (``parse_sharded``: each rank parses ~2/N of the files instead of all).
     -> list of [L_i, 21] ddG tables (device tensors) in the original order — or (tables, [L_i] int32 counts)."""
-    lengths = [len(p["S"]) for p in proteins]
+    lengths = [len(p["S"]) for p in proteins] if lengths is None else [int(x) for x in lengths]
+    assert len(lengths) == len(proteins)
     C = 22 if centrality else 21
 
     def compute(ids):
@@ -130,6 +133,33 @@ def ssm_scan(engine, proteins: Sequence[dict], group=None, gather: bool = True, 
     ddg = [None if t is None else t[:, :21] for t in tables]
     cen = [None if t is None else t[:, 21].round().to(torch.int32) for t in tables]
     return ddg, cen
+
+
+def parse_sharded(paths: Sequence[str], chains: Optional[Sequence] = None, group=None, k_neighbors: int = 48,
+                  parse=None):
+    """Parse a many-PDB job without every rank reading every file: rank r parses files r, r + N, ... (a cheap, evenly
+    spread length pre-pass), the lengths and sequences are exchanged (a few bytes per residue, ``all_gather_object``), the
+    LPT partition is computed from the lengths, and each rank parses only the files of its own shard that it has not read yet.
+    -> (proteins: list with this rank's shard filled in and ``None`` elsewhere, lengths, seqs, names). World of one: everything."""
+    from . import native_pdb
+    parse = parse or native_pdb.parse_pdbs
+    n = len(paths)
+    chains = list(chains) if chains is not None else [None] * n
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = list(range(rank, n, world))
+    got = dict(zip(mine, parse([paths[i] for i in mine], [chains[i] for i in mine])))
+    info = {i: (len(p["S"]), p["seq"], p["name"]) for i, p in got.items()}
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, info, group=group)
+        info = {k: v for part in parts for k, v in part.items()}
+    lengths = [info[i][0] for i in range(n)]
+    shard = partition_proteins(lengths, world, k_neighbors)[rank]
+    missing = [i for i in shard if i not in got]
+    got.update(zip(missing, parse([paths[i] for i in missing], [chains[i] for i in missing])))
+    proteins = [got[i] if i in set(shard) else None for i in range(n)]
+    return proteins, lengths, [info[i][1] for i in range(n)], [info[i][2] for i in range(n)]
 
 
 def select_mutations(tables: Sequence[torch.Tensor], triples) -> torch.Tensor:

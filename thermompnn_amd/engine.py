@@ -104,10 +104,10 @@ class Engine:
                                            tensors=self.w.tensors)
         return self._alt[precision]
 
-    def _raise_status(self, what: str) -> int:
+    def _raise_status(self, what: str, status: Optional[torch.Tensor] = None) -> int:
         """Reads the device status word (ONE 4-byte D2H copy = a stream sync) and raises on TMPNN_STATUS_MAXLEN;
         returns the remaining bits (TMPNN_STATUS_RANGE is the caller's to handle)."""
-        st = int(self._status.item())
+        st = int((self._status if status is None else status).item())
         if st & _lib.STATUS_MAXLEN:
             check(self.lib.tmpnn_status_error(_lib.STATUS_MAXLEN), what)
         return st
@@ -216,7 +216,7 @@ class Engine:
     def ssm_forward(self, X, S, mask, residue_idx, chain_enc, offsets, max_len: Optional[int] = None,
                     want_ddg: bool = True, want_hidden: bool = False, want_log_probs: bool = False,
                     want_E_idx: bool = False, out: Optional[dict] = None, check_status: bool = True,
-                    precision: Optional[str] = None):
+                    precision: Optional[str] = None, _private: Optional[dict] = None):
         """Packed inputs ([T,4,3], [T], ...) -> dict(ddg [T,21], hidden [3,T,128], log_probs [T,21], E_idx [T,48]).
 
         ``check_status`` (default) reads the 4-byte device status word after the launches — one stream sync — and
@@ -224,7 +224,8 @@ class Engine:
           * on a non-finite ddG / log-probability (fp16 overflow of the f16x2 path) reruns the batch once at
             ``retry_precision`` with a warning, or raises TmpnnRangeError.
         Throughput loops pass ``check_status=False`` (nothing syncs; call ``check_last_status()`` when convenient).
-        ``precision`` overrides the engine's precision for this call."""
+        ``precision`` overrides the engine's precision for this call. (``_private``: workspace / status word owned by a
+        captured graph instead of the engine's shared ones, see ``capture_graph``.)"""
         max_len = self._max_len(offsets, max_len)
         X, mask = self._f32(X), self._f32(mask)
         S, ridx, cenc, offsets = self._i32(S), self._i32(residue_idx), self._i32(chain_enc), self._i32(offsets)
@@ -240,20 +241,28 @@ class Engine:
             res["log_probs"] = torch.empty((T, VOCAB), dtype=torch.float32, device=dev)
         if want_E_idx and "E_idx" not in res:
             res["E_idx"] = torch.empty((T, KS), dtype=torch.int32, device=dev)
-        ws = self._workspace(self.lib.tmpnn_workspace_bytes(T))
+        need = self.lib.tmpnn_workspace_bytes(T)
+        if _private is not None:
+            if _private.get("ws") is None or _private["ws"].numel() < need:
+                _private["ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+            if _private.get("status") is None:
+                _private["status"] = torch.zeros(1, dtype=torch.int32, device=dev)
+            ws, status = _private["ws"], _private["status"]
+        else:
+            ws, status = self._workspace(need), self._status
 
         def run(w: Weights):
             check(self.lib.tmpnn_ssm_forward(w.handle, _ptr(X), _ptr(S), _ptr(mask), _ptr(ridx), _ptr(cenc), _ptr(offsets),
                                              N, T, max_len, self.K, _ptr(res.get("ddg") if want_ddg else None),
                                              _ptr(res.get("hidden") if want_hidden else None),
                                              _ptr(res.get("log_probs") if want_log_probs else None),
-                                             _ptr(res.get("E_idx") if want_E_idx else None), _ptr(self._status), _ptr(ws),
+                                             _ptr(res.get("E_idx") if want_E_idx else None), _ptr(status), _ptr(ws),
                                              ws.numel(), _stream()), "tmpnn_ssm_forward")
 
         used = precision or self.precision
         run(self.weights_for(used))
         if check_status and T > 0 and N > 0:
-            st = self._raise_status("tmpnn_ssm_forward")
+            st = self._raise_status("tmpnn_ssm_forward", status)
             if st & _lib.STATUS_RANGE:
                 retry = self.retry_precision
                 if used != "f16x2" or not retry or retry == used:
@@ -261,7 +270,7 @@ class Engine:
                 warnings.warn(f"ThermoMPNN HIP engine: non-finite result in {used} (an operand left the fp16 range); "
                               f"rerunning this batch at precision {retry}", RuntimeWarning, stacklevel=2)
                 run(self.weights_for(retry))
-                st = self._raise_status("tmpnn_ssm_forward")
+                st = self._raise_status("tmpnn_ssm_forward", status)
                 if st:
                     check(self.lib.tmpnn_status_error(st), f"tmpnn_ssm_forward[{retry}]")
         return res
@@ -269,23 +278,40 @@ class Engine:
     def capture_graph(self, X, S, mask, residue_idx, chain_enc, offsets, max_len: int, out: Optional[dict] = None, **want):
         """Capture ONE fused forward (its ~20 launches + the status memset) into a hipGraph: -> (graph, out). ``graph.replay()``
         reruns it on the captured tensors — refill X / S / ... in place for a new protein of the same length. The C-ABI
-        never allocates or synchronises, so the call sequence captures as is; the workspace and the outputs are
-        allocated by a warm-up run before the capture. Removes the per-launch CPU cost that dominates a single small
-        protein (20 launches for ~0.2 ms of GPU work)."""
+        never allocates or synchronises, so the call sequence captures as is. Removes the per-launch CPU cost that
+        dominates a single small protein (20 launches for ~0.2 ms of GPU work).
+
+        Every buffer whose address is baked into the captured launches belongs to the GRAPH, not to the engine: the
+        workspace and the status word are allocated here (the engine's shared workspace is reallocated when a later call
+        needs more bytes — a graph that pointed into it would replay on freed memory), and the graph keeps them, the
+        inputs, the outputs and the weight handle alive. ``check_graph_status(graph)`` reads the graph's status word."""
         X, mask = self._f32(X), self._f32(mask)
         S, ridx, cenc, offsets = self._i32(S), self._i32(residue_idx), self._i32(chain_enc), self._i32(offsets)
-        kw = dict(max_len=int(max_len), check_status=False, **want)
+        priv: dict = {}
+        kw = dict(max_len=int(max_len), check_status=False, _private=priv, **want)
+        w = self.weights_for(want.get("precision") or self.precision)
+        cur = torch.cuda.current_stream(self.device)
         side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
+        side.wait_stream(cur)
         with torch.cuda.stream(side):
             out = self.ssm_forward(X, S, mask, ridx, cenc, offsets, out=out, **kw)        # warm-up: buffers exist afterwards
-        torch.cuda.current_stream(self.device).wait_stream(side)
+        keep = [X, S, mask, ridx, cenc, offsets, priv["ws"], priv["status"], *out.values()]
+        for t in keep:                      # allocated / first used on the side stream, replayed from others later
+            t.record_stream(cur)
+        cur.wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self.ssm_forward(X, S, mask, ridx, cenc, offsets, out=out, **kw)
-        graph._tmpnn_keepalive = (X, S, mask, ridx, cenc, offsets, out)                    # captured pointers stay valid
+        graph._tmpnn_keepalive = (keep, out, priv, w)                                      # captured pointers stay valid
+        graph._tmpnn_status = priv["status"]
         return graph, out
+
+    def check_graph_status(self, graph) -> None:
+        """Raise if the last replay of a graph from ``capture_graph`` flagged a range / max_len problem (syncs)."""
+        st = int(graph._tmpnn_status.item())
+        if st:
+            check(self.lib.tmpnn_status_error(st), "tmpnn_ssm_forward[graph]")
 
     def check_last_status(self) -> None:
         """Raise if the most recent ``ssm_forward(check_status=False)`` flagged a range / max_len problem (syncs)."""

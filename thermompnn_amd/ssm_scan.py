@@ -38,13 +38,15 @@ def retrieve_best_mutants(ddg_table: np.ndarray, allow_cys: bool = True) -> List
     return [AA20[i] for i in np.argmin(t, axis=1)]
 
 
-def scan_proteins(engine, proteins: Sequence[dict], centrality: bool = False, chunk_residues: int = 1 << 18, group=None):
-    """proteins: dicts from native_pdb.parse_pdb. -> (list of [L,21] ddG arrays, list of neighbour-count arrays or None).
+def scan_proteins(engine, proteins: Sequence[Optional[dict]], centrality: bool = False, chunk_residues: int = 1 << 18, group=None,
+                  lengths: Optional[Sequence[int]] = None):
+    """proteins: dicts from native_pdb.parse_pdb (with ``lengths``: only this rank's shard, ``None`` elsewhere — dist.parse_sharded).
+    -> (list of [L,21] ddG arrays, list of neighbour-count arrays or None).
     Sharded over ``group``'s ranks when torch.distributed is initialised (every rank gets every table back); processed in
     ragged chunks of at most ``chunk_residues`` residues. Non-finite results never reach the caller: the engine reruns
     an overflowing f16x2 batch in bf16x3 or raises (Engine.ssm_forward)."""
     from .dist import ssm_scan
-    res = ssm_scan(engine, proteins, group=group, centrality=centrality, chunk_residues=chunk_residues)
+    res = ssm_scan(engine, proteins, group=group, centrality=centrality, chunk_residues=chunk_residues, lengths=lengths)
     tables, cen = res if centrality else (res, None)
     flat = torch.cat([t.reshape(-1) for t in tables]).cpu().numpy() if tables else np.zeros(0, np.float32)   # one D2H copy
     out, pos = [], 0
@@ -60,7 +62,7 @@ def read_mutation_list(path: str, proteins: Sequence[dict]):
     """CSV with columns pdb,position,mutation[,wildtype] -> int64 [M,3] triples (protein index, position, aa index).
     ``pdb`` matches the parsed structure's name; a stated wildtype must agree with the structure's residue (the
     reference asserts this too, custom_inference.py:86-87)."""
-    by_name = {p["name"]: i for i, p in enumerate(proteins)}
+    by_name = {p["name"]: i for i, p in enumerate(proteins)}          # (only "name" and "seq" of every entry are used)
     out = []
     with open(path, newline="") as fh:
         for r in csv.DictReader(fh):
@@ -120,16 +122,22 @@ def main(argv=None):
     ap.add_argument("--centrality", action="store_true", default=False, help="Calculate centrality value for each residue (# neighbors).")
     ap.add_argument("--mutations", default="", help="CSV (pdb,position,mutation): write only these mutants")
     ap.add_argument("--precision", default=None, choices=["f16x2", "bf16x3", "fp32"])
+    ap.add_argument("--allow_pickle", action="store_true", default=False,
+                    help="read --model_path with the unrestricted pickle loader (it can execute code from the file); the default "
+                         "restricted loader already reads Lightning checkpoints such as thermoMPNN_default.pt")
     args = ap.parse_args(argv)
 
     from . import dist as tdist
     from .custom_inference import load_model
     rank, world, device = tdist.init_from_env()
-    model = load_model(args.model_path, args.thermompnn_dir, args.synthetic_weights, device=device, precision=args.precision)
+    model = load_model(args.model_path, args.thermompnn_dir, args.synthetic_weights, device=device, precision=args.precision,
+                       allow_pickle=args.allow_pickle or None)
     engine = model.engine()
-    proteins = native_pdb.parse_pdbs(args.pdbs, [args.chain] * len(args.pdbs))
+    # every rank parses ~2/N of the files (a strided length pre-pass + the rest of its own LPT shard), not all of them
+    shard, lengths, seqs, names = tdist.parse_sharded(args.pdbs, [args.chain] * len(args.pdbs), k_neighbors=engine.K)
     with torch.cuda.device(engine.device):
-        tables, neigh = scan_proteins(engine, proteins, centrality=args.centrality)
+        tables, neigh = scan_proteins(engine, shard, centrality=args.centrality, lengths=lengths)
+    proteins = [{"seq": s_, "name": n_} for s_, n_ in zip(seqs, names)]     # what the writer needs of every protein
     if rank == 0:
         rows = []
         if args.mutations:

@@ -62,13 +62,13 @@ class ProteinMPNNBaseline(_EngineOwner):
         return out, log_probs
 
 
-def get_trained_model(model_name, config, checkpt_dir="models/", override_custom=False):
+def get_trained_model(model_name, config, checkpt_dir="models/", override_custom=False, allow_pickle=None):
     """Load a ThermoMPNN Lightning checkpoint into the HIP-backed TransferModel (reference :78-84) without
     importing Lightning: the ``model.`` prefix of TransferModelPL is stripped by the loader."""
     import os
     path = model_name if override_custom else os.path.join(config.platform.thermompnn_dir, checkpt_dir, model_name)
     model = TransferModel(config)
-    model.load_state_dict(load_thermompnn_checkpoint(path))
+    model.load_state_dict(load_thermompnn_checkpoint(path, allow_pickle=allow_pickle))
     return model
 
 

@@ -88,30 +88,39 @@ def transfer_param_shapes() -> "OrderedDict[str, tuple]":
     return s
 
 
-def _draw(rng: np.random.Generator, name: str, shape: tuple) -> np.ndarray:
+STYLES = ("xavier", "hot")
+
+
+def _draw(rng: np.random.Generator, name: str, shape: tuple, style: str = "xavier") -> np.ndarray:
+    """``style`` 'xavier': Xavier-uniform matrices, N(0, 0.02) biases, LayerNorm gamma 1 +- 0.1 / beta +- 0.1.
+    'hot': a deliberately heavy draw for the accuracy margin of the split-precision kernels — matrices x 3, biases x 5,
+    LayerNorm gamma uniform in [-2, 2] and beta in [-0.5, 0.5]: activations one to two orders of magnitude above the
+    Xavier draw's, still finite in fp32 through the reference."""
+    hot = style == "hot"
     leaf = name.rsplit(".", 1)[-1]
     if name.startswith("ddg_out"):
         return np.full(shape, 1.7 if leaf == "weight" else -0.3, dtype=np.float32)
     if ".norm" in name or "norm_edges" in name:
         if leaf == "weight":
-            return (1.0 + rng.uniform(-0.1, 0.1, shape)).astype(np.float32)
-        return rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+            return (rng.uniform(-2.0, 2.0, shape) if hot else 1.0 + rng.uniform(-0.1, 0.1, shape)).astype(np.float32)
+        return rng.uniform(-0.5, 0.5, shape).astype(np.float32) if hot else rng.uniform(-0.1, 0.1, shape).astype(np.float32)
     if leaf == "bias":
-        return rng.normal(0.0, 0.02, shape).astype(np.float32)
-    if len(shape) == 3:                                   # conv taps: all nine non-zero
-        bound = math.sqrt(6.0 / (shape[0] + shape[1]))
-    else:
-        bound = math.sqrt(6.0 / (shape[0] + shape[1]))    # Xavier-uniform (protein_mpnn_utils.py:1217-1219)
+        return rng.normal(0.0, 0.1 if hot else 0.02, shape).astype(np.float32)
+    bound = math.sqrt(6.0 / (shape[0] + shape[1]))        # Xavier-uniform (protein_mpnn_utils.py:1217-1219); conv taps: all nine non-zero
+    if hot:
+        bound *= 3.0
     return rng.uniform(-bound, bound, shape).astype(np.float32)
 
 
-def synthetic_state_dict(seed: int = 0, which: str = "transfer") -> "OrderedDict[str, torch.Tensor]":
-    """Deterministic synthetic weights. ``which`` = 'transfer' (full TransferModel tree) or 'mpnn'."""
+def synthetic_state_dict(seed: int = 0, which: str = "transfer", style: str = "xavier") -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic synthetic weights. ``which`` = 'transfer' (full TransferModel tree) or 'mpnn'; ``style`` see _draw."""
+    if style not in STYLES:
+        raise ValueError(f"style={style!r}: expected one of {STYLES}")
     rng = np.random.default_rng(seed)
     shapes = transfer_param_shapes() if which == "transfer" else mpnn_param_shapes()
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for name, shape in shapes.items():
-        out[name] = torch.from_numpy(_draw(rng, name, shape))
+        out[name] = torch.from_numpy(_draw(rng, name, shape, style))
     return out
 
 
@@ -140,14 +149,91 @@ def save_lightning_checkpoint(path, transfer_sd) -> None:
     torch.save({"state_dict": OrderedDict(("model." + k, v) for k, v in transfer_sd.items())}, path)
 
 
+class _Opaque:
+    """Stand-in for every pickled global that is not a tensor / plain-container constructor: constructing it, calling it,
+    setting its state or filling it does nothing. An OmegaConf config, an optimizer object or a hostile ``__reduce__``
+    all come out as inert ``_Opaque`` instances — nothing from the file is imported or executed."""
+
+    def __new__(cls, *a, **k):
+        return object.__new__(cls)
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return self
+
+    def __setstate__(self, state):
+        pass
+
+    def __setitem__(self, k, v):
+        pass
+
+    def append(self, v):
+        pass
+
+    def extend(self, vs):
+        pass
+
+    def add(self, v):
+        pass
+
+    def update(self, *a, **k):
+        pass
+
+
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "set"), ("builtins", "frozenset"),
+    ("builtins", "list"), ("builtins", "dict"), ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"),
+    ("builtins", "complex"), ("builtins", "bytearray"), ("builtins", "slice"), ("builtins", "range"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
+    ("torch.serialization", "_get_layout"), ("torch._tensor", "_rebuild_from_type_v2"),
+    # numpy arrays of plain dtypes / of Python strings (the reference's dataset_splits/*.pkl)
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+}
+
+
+def _safe_pickle_module():
+    """A ``pickle_module`` for ``torch.load`` / a plain loader whose Unpickler resolves ONLY the constructors above (plus
+    torch's dtypes and storage classes, which torch's own wrapper handles) and maps every other global to ``_Opaque``."""
+    import pickle
+    import types
+
+    class SafeUnpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if (module, name) in _SAFE_GLOBALS:
+                return super().find_class(module, name)
+            if module == "torch" and (name.endswith("Storage") or name in {d for d in dir(torch) if isinstance(getattr(torch, d), torch.dtype)}):
+                return super().find_class(module, name)
+            return _Opaque
+
+    mod = types.ModuleType("tmpnn_safe_pickle")
+    mod.Unpickler = SafeUnpickler
+    mod.load = lambda f, **kw: SafeUnpickler(f, **kw).load()
+    mod.loads = lambda b, **kw: SafeUnpickler(__import__("io").BytesIO(b), **kw).load()
+    mod.__name__ = "pickle"
+    return mod
+
+
+def safe_unpickle(path):
+    """Plain-pickle files of containers / numpy arrays (the reference's split dictionaries) without executing their globals."""
+    with open(path, "rb") as fh:
+        return _safe_pickle_module().load(fh)
+
+
 def load_thermompnn_checkpoint(path, allow_pickle: bool = None):
     """Read a TransferModelPL checkpoint without importing Lightning (train_thermompnn.py:28-40 registers the
     TransferModel as ``self.model``): keeps ONLY the ``model.*`` entries of ``state_dict`` (Lightning-level buffers,
     metric states, optimizer state and ``hyper_parameters`` are dropped) and strips the prefix.
 
     The file is read with ``torch.load(weights_only=True)`` (tensors and plain containers only). Checkpoints whose
-    ``hyper_parameters`` hold arbitrary Python objects (an OmegaConf config) need the pickle loader, which executes code
-    from the file: that is an explicit opt-in — ``allow_pickle=True`` or TMPNN_ALLOW_PICKLE=1 — for files you trust."""
+    ``hyper_parameters`` hold arbitrary Python objects (the published ``thermoMPNN_default.pt`` carries an OmegaConf
+    config) fail that load; they are then read through a RESTRICTED unpickler that builds tensors and plain containers
+    and turns every other pickled global into an inert placeholder — nothing from the file is imported or executed, so
+    the reference's standard checkpoint loads out of the box (thermompnn_benchmarking.py:78-84 loads it with Lightning).
+    ``allow_pickle=True`` / TMPNN_ALLOW_PICKLE=1 selects the unrestricted pickle loader instead (files you trust)."""
     import os
     import pickle
     if allow_pickle is None:
@@ -155,19 +241,27 @@ def load_thermompnn_checkpoint(path, allow_pickle: bool = None):
     try:
         ckpt = torch.load(path, map_location="cpu", weights_only=True)
     except (pickle.UnpicklingError, RuntimeError) as e:
-        if not allow_pickle:
-            raise RuntimeError(f"{path}: not loadable with weights_only=True ({str(e).splitlines()[0][:200]}). If you trust "
-                               "this file, pass allow_pickle=True (or set TMPNN_ALLOW_PICKLE=1) to use the pickle "
-                               "loader, which can execute code embedded in the checkpoint.") from e
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        if allow_pickle:
+            ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        else:
+            try:
+                ckpt = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_safe_pickle_module())
+            except Exception as e2:
+                raise RuntimeError(f"{path}: not loadable with weights_only=True ({str(e).splitlines()[0][:200]}) nor with the "
+                                   f"restricted unpickler ({str(e2).splitlines()[0][:200]}). If you trust this file, pass "
+                                   "allow_pickle=True (or set TMPNN_ALLOW_PICKLE=1) to use the pickle loader, which can "
+                                   "execute code embedded in the checkpoint.") from e2
     out = OrderedDict()
     if isinstance(ckpt, dict) and "state_dict" in ckpt:
         for k, v in ckpt["state_dict"].items():
-            if k.startswith("model."):
+            if k.startswith("model.") and isinstance(v, torch.Tensor):
                 out[k[len("model."):]] = v
         if not out:
             raise KeyError(f"{path}: 'state_dict' has no 'model.*' entries (not a TransferModelPL checkpoint?)")
-    else:                                       # a bare TransferModel state dict
+    elif isinstance(ckpt, dict):                # a bare TransferModel state dict
         for k, v in ckpt.items():
-            out[k[len("model."):] if k.startswith("model.") else k] = v
+            if isinstance(v, torch.Tensor):
+                out[k[len("model."):] if k.startswith("model.") else k] = v
+    else:
+        raise KeyError(f"{path}: not a checkpoint dictionary")
     return out
