@@ -317,3 +317,45 @@ __device__ __forceinline__ void row_stats_finish8b(const float *stat_row, float 
     }
     rstd = __builtin_amdgcn_rsqf((m2 + 16.f * dd) * (1.0f / 128.0f) + 1e-5f);     // v_rsq_f32, 1 ulp
 }
+
+// ------------------------------------------------------------------------------------------------
+// Cheaper form of the same fused statistics (edge update, f16x2): 20 + 11 VALU operations per row instead of 28 + 33.
+//  * partial: the wavefront's 16 columns of a row (4 lanes x 4 values) as an exact two-pass — sum over the 16 values (plain adds,
+//    permlane swaps), mean, squared deviations from THAT mean, summed the same way — no Chan merge inside the wavefront;
+//  * finish: the 8 partials of a row are spread over 8 lanes of the half-wavefront that owns the row in the row phase (lane k
+//    loads partial k with one ds_read_b64) and merged with two 8-lane DPP all-reduces (quad_perm xor 1, xor 2, row_half_mirror)
+//    instead of every lane reading and merging all 8 partials by itself;
+//  * the statistics rows are TM_STAT_LD = 18 floats apart: the 16 lanes of a q = 0 group write 8 bytes each at bank
+//    18 m + 2 wv (mod 32) — all distinct (a 16-float pitch put them on two bank pairs: 8-way conflicts).
+// Deterministic per row (fixed merge order); not bit-identical to row_stats_partial1b / finish8b, which the bf16x3 kernel keeps.
+// ------------------------------------------------------------------------------------------------
+#define TM_STAT_LD 18
+__device__ __forceinline__ float swap_add16(float x) {      // x(lane) + x(lane ^ 16) on every lane
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+__device__ __forceinline__ float swap_add32(float x) {      // x(lane) + x(lane ^ 32)
+    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+__device__ __forceinline__ void row_stats_partial16(const f4 v, float *stat_slot, int q) {
+    const float s = swap_add32(swap_add16((v.x + v.y) + (v.z + v.w)));
+    const float mean = s * 0.0625f;
+    const f4 d = v - mean;
+    const float m2 = swap_add32(swap_add16(__builtin_fmaf(d.w, d.w, __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x)))));
+    if (q == 0) *reinterpret_cast<f2 *>(stat_slot) = f2{mean, m2};
+}
+__device__ __forceinline__ float allreduce8_dpp(float x) {  // sum over each aligned group of 8 lanes, on every lane
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true));    // row_half_mirror
+    return x;
+}
+// stat_row = &s_stat[row][0]; every lane of the half-wavefront that owns `row` calls this
+__device__ __forceinline__ void row_stats_finish8d(const float *stat_row, int lane, float &mean, float &rstd) {
+    const f2 p = *reinterpret_cast<const f2 *>(stat_row + 2 * (lane & 7));
+    mean = allreduce8_dpp(p.x) * 0.125f;
+    const float d = p.x - mean;
+    const float m2 = allreduce8_dpp(__builtin_fmaf(16.f * d, d, p.y));
+    rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(m2, 1.0f / 128.0f, 1e-5f));
+}
