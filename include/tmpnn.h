@@ -81,9 +81,12 @@ int tmpnn_num_tensors(void);
 const char *tmpnn_tensor_name(int index);       /* NULL if out of range */
 int64_t tmpnn_tensor_numel(int index);          /* -1 if out of range */
 
-/* Device bytes the library needs for derived tables (positional table, per-decoder-layer sequence
- * tables, centre tap of the feature convolution). */
+/* Device bytes the library needs for derived data: positional table, per-decoder-layer sequence tables, centre tap of the
+ * feature convolution (0.8 MB) and — for "f16x2" handles only — the f16 fragment images of the weight blocks (7.2 MB).
+ * tmpnn_weights_packed_bytes() is the upper bound over the precisions; _p gives the size for one precision (NULL = the
+ * default; 0 for an unknown name). */
 size_t tmpnn_weights_packed_bytes(void);
+size_t tmpnn_weights_packed_bytes_p(const char *precision);
 
 /* Replaces: get_protein_mpnn()'s load_state_dict (transfer_model.py:17-37) and the Lightning
  * checkpoint load (analysis/thermompnn_benchmarking.py:78-84) — the host reads the file, this call

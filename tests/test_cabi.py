@@ -45,7 +45,11 @@ def test_tensor_table_matches_python_state_dict_order():
     assert lib.tmpnn_tensor_name(130) is None and lib.tmpnn_tensor_numel(-1) == -1
     assert lib.tmpnn_version() == 200
     assert lib.tmpnn_workspace_bytes(256) > 256 * 48 * 128 * 4
-    assert lib.tmpnn_weights_packed_bytes() == (66 * 128 + 3 * 21 * 128 + 384 * 384) * 4 + 110 * 65536
+    tables = (66 * 128 + 3 * 21 * 128 + 384 * 384) * 4
+    assert lib.tmpnn_weights_packed_bytes() == tables + 110 * 65536
+    assert lib.tmpnn_weights_packed_bytes_p(b"f16x2") == tables + 110 * 65536            # fragment images: f16x2 handles only
+    assert lib.tmpnn_weights_packed_bytes_p(b"bf16x3") == lib.tmpnn_weights_packed_bytes_p(b"fp32") == tables
+    assert lib.tmpnn_weights_packed_bytes_p(b"fp64") == 0
 
 
 def test_argument_errors_do_not_need_a_gpu():

@@ -925,6 +925,41 @@ def test_range_overflow_is_detected_and_retried(synthetic_weights):
         strict.ssm_forward(*args)
 
 
+def test_range_flag_covers_the_head_and_hidden_only_forwards(synthetic_weights):
+    """(1) an overflow INSIDE the head's own f16x2 GEMMs (centre tap x 1e6: relu(Wc x + bc) leaves the fp16 range while
+    every fp32 value stays finite) used to come out of the ReLUs as a finite, wrong ddG with no flag; (2) a forward that only
+    returns hidden states has no head / log-probability kernel to look at them. Both raise TMPNN_STATUS_RANGE now."""
+    import warnings
+    from thermompnn_amd._lib import TmpnnRangeError
+    from thermompnn_amd.engine import Engine
+    p = packed_inputs(load_golden("syn_L32"))
+    args = (p["X"], p["S"], p["mask"], p["ridx"], p["cenc"], p["offsets"])
+    W = {k: v.clone() for k, v in synthetic_weights.items()}
+    W["light_attention.feature_convolution.weight"] = W["light_attention.feature_convolution.weight"] * 1e6
+    want = Engine(W, "cuda:0", 48, precision="fp32").ssm_forward(*args)["ddg"]
+    assert bool(torch.isfinite(want).all()) and float(want.abs().max()) > 1e3
+    strict = Engine(W, "cuda:0", 48, precision="f16x2", retry_precision=None)
+    with pytest.raises(TmpnnRangeError):
+        strict.ssm_forward(*args)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = Engine(W, "cuda:0", 48, precision="f16x2").ssm_forward(*args)["ddg"]          # reruns in bf16x3
+    assert any("bf16x3" in str(w.message) for w in rec)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    # a decoder weight: the poisoned state is caught at the head's input
+    W2 = {k: v.clone() for k, v in synthetic_weights.items()}
+    W2["prot_mpnn.decoder_layers.2.W1.weight"] = W2["prot_mpnn.decoder_layers.2.W1.weight"] * 1e7
+    with pytest.raises(TmpnnRangeError):
+        Engine(W2, "cuda:0", 48, precision="f16x2", retry_precision=None).ssm_forward(*args)
+    # hidden states only
+    W3 = {k: v.clone() for k, v in synthetic_weights.items()}
+    W3["prot_mpnn.features.edge_embedding.weight"] = W3["prot_mpnn.features.edge_embedding.weight"] * 1e6
+    with pytest.raises(TmpnnRangeError):
+        Engine(W3, "cuda:0", 48, precision="f16x2", retry_precision=None).ssm_forward(*args, want_ddg=False, want_hidden=True)
+    ok = Engine(synthetic_weights, "cuda:0", 48).ssm_forward(*args, want_ddg=False, want_hidden=True)
+    assert bool(torch.isfinite(ok["hidden"]).all())
+
+
 def test_max_len_is_guarded(engine):
     """A max_len below the longest protein can no longer overrun the kNN kernel's LDS row: host offsets are checked in
     Python, device offsets by the kernel (empty rows + TMPNN_STATUS_MAXLEN)."""

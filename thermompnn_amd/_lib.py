@@ -29,6 +29,7 @@ SIGNATURES = {
     "tmpnn_tensor_name": (C.c_char_p, [_i]),
     "tmpnn_tensor_numel": (_i64, [_i]),
     "tmpnn_weights_packed_bytes": (_sz, []),
+    "tmpnn_weights_packed_bytes_p": (_sz, [C.c_char_p]),
     "tmpnn_status_error": (_i, [C.c_int32]),
     "tmpnn_weights_create": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _p, _sz, _p]),
     "tmpnn_weights_create_p": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _p, _sz, C.c_char_p, _p]),

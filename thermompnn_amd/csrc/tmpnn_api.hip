@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <new>
 #include <string>
@@ -112,12 +113,16 @@ static int default_mode() {                  // TMPNN_PRECISION, read once; an u
 static thread_local int g_mode = -1;         // mode of the API call in progress (TmModeScope), -1 = none
 static thread_local const tmpnn_weights *g_cur_w = nullptr;
 const tmpnn_weights *tm_cur_weights() { return g_cur_w; }
-const char *tm_find_wimg(const float *base) {
+const char *tm_find_wimg(const float *base) {       // wimg[] is sorted by base address at create time: binary search
     const tmpnn_weights *w = g_cur_w;
     if (!w || !base) return nullptr;
-    for (int i = 0; i < w->n_wimg; ++i)
-        if (w->wimg[i].base == base) return w->wimg[i].img;
-    return nullptr;
+    int lo = 0, hi = w->n_wimg;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (w->wimg[mid].base < base) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < w->n_wimg && w->wimg[lo].base == base ? w->wimg[lo].img : nullptr;
 }
 int tm_matmul_mode() {
     if (g_mode >= 0) return g_mode;
@@ -200,8 +205,14 @@ extern "C" int64_t tmpnn_tensor_numel(int i) {
 
 static const size_t POS_TABLE_FLOATS = 66 * TMPNN_HID, SEQ_TABLE_FLOATS = TMPNN_VOCAB * TMPNN_HID,
                     CONV_CENTER_FLOATS = 384 * 384;
-extern "C" size_t tmpnn_weights_packed_bytes(void) {
-    return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float) + (size_t)TM_N_WIMG * TM_WIMG_BYTES;
+static size_t packed_bytes_for(int mode) {    // the f16 fragment images exist for f16x2 handles only (nothing else reads them)
+    return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float) +
+           (mode == TM_MM_F16X2 ? (size_t)TM_N_WIMG * TM_WIMG_BYTES : 0);
+}
+extern "C" size_t tmpnn_weights_packed_bytes(void) { return packed_bytes_for(TM_MM_F16X2); }   // upper bound over the precisions
+extern "C" size_t tmpnn_weights_packed_bytes_p(const char *precision) {
+    const int mode = precision ? parse_mode(precision) : default_mode();
+    return mode < 0 ? 0 : packed_bytes_for(mode);
 }
 
 extern "C" int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *tensors, int n_tensors, void *packed,
@@ -220,9 +231,9 @@ extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const 
     if (n_tensors != TMPNN_N_MPNN_TENSORS && n_tensors != TMPNN_N_TENSORS)
         return tm_set_error(TMPNN_E_INVALID, "weights_create: n_tensors must be %d or %d, got %d", TMPNN_N_MPNN_TENSORS,
                             TMPNN_N_TENSORS, n_tensors);
-    if (packed_bytes < tmpnn_weights_packed_bytes())
+    if (packed_bytes < packed_bytes_for(mode))
         return tm_set_error(TMPNN_E_WORKSPACE, "weights_create: packed buffer %zu < %zu bytes", packed_bytes,
-                            tmpnn_weights_packed_bytes());
+                            packed_bytes_for(mode));
     if (((uintptr_t)packed & 15) != 0) return tm_set_error(TMPNN_E_INVALID, "weights_create: packed buffer must be 16-byte aligned");
     for (int i = 0; i < n_tensors; ++i)
         if (!tensors[i] || ((uintptr_t)tensors[i] & 15) != 0)
@@ -289,7 +300,7 @@ extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const 
     for (int l = 0; l < 3; ++l) { w->seq_table[l] = p; p += SEQ_TABLE_FLOATS; }
     w->conv_center = p; p += CONV_CENTER_FLOATS;
     int rc = launch_prep_tables(w, (hipStream_t)stream);
-    {   // fragment images of every 128 x 128 block the node kernels multiply by (see WImg)
+    if (mode == TM_MM_F16X2) {   // fragment images of every 128 x 128 block the f16x2 kernels multiply by (see WImg); no other mode reads them
         char *img = (char *)p;
         auto add = [&](const float *base, int ld, int n_rows = 128, int k_valid = 128) {
             if (rc != TMPNN_OK || w->n_wimg >= TM_N_WIMG) return;
@@ -315,6 +326,7 @@ extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const 
             add(d.W1, 512); add(d.W1 + 384, 512);
             add(d.W1 + 128, 512); add(d.W2, 128);
         }
+        std::sort(w->wimg, w->wimg + w->n_wimg, [](const WImg &x, const WImg &y) { return x.base < y.base; });   // tm_find_wimg searches it
     }
     if (rc != TMPNN_OK) { delete w; return rc; }
     *out = w;
@@ -570,5 +582,8 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     }
     if (ddg) TRY(launch_head(w, hV[3], hV[2], S, T, ddg, nullptr, status_opt, st));
     if (log_probs_opt) TRY(launch_log_probs(w, hV[3], T, log_probs_opt, status_opt, st));
+    // hidden states only: neither of the kernels above has looked at the last decoder state (a poisoned value anywhere upstream
+    // has reached it through its neighbours by now)
+    if (!ddg && !log_probs_opt && hidden_opt) TRY(launch_range_check(hV[3], T * TMPNN_HID, status_opt, st));
     return TMPNN_OK;
 }

@@ -132,8 +132,29 @@ __device__ __forceinline__ f2 pk_horner(f2 q, f2 t, float c) {
     return __builtin_elementwise_fma(q, t, f2{c, c});
 #endif
 }
+// TM_GELU_FORM: 1 (default) = exponent polynomial P of degree 6 with a free constant term, fitted to the error of gelu itself
+// (tools/fit_gelu.py: max abs error 2.8e-7 — the fp32 rounding floor of x Phi(x) is 2.4e-7) — 6 packed Horner steps;
+// 0 = round 1's degree-8 fit of the exponent with the constant pinned to -1 (2.4e-7, 10 steps): same accuracy, 4 more VALU
+// instructions per pair of values, and these kernels are paced by their VALU instruction COUNT.
+#ifndef TM_GELU_FORM
+#define TM_GELU_FORM 1
+#endif
+#ifndef TM_ABL_NOGELU
+#define TM_ABL_NOGELU 0
+#endif
 __device__ __forceinline__ f2 gelu2(f2 x) {
+#if TM_ABL_NOGELU
+    return x;
+#endif
     const f2 t = f2{fminf(fabsf(x.x), 5.656854249f), fminf(fabsf(x.y), 5.656854249f)};
+#if TM_GELU_FORM == 1
+    f2 q = __builtin_elementwise_fma(f2{3.309543916e-05f, 3.309543916e-05f}, t, f2{-7.692427171e-04f, -7.692427171e-04f});
+    q = pk_horner(q, t, 8.080792133e-03f);
+    q = pk_horner(q, t, -5.341222090e-02f);
+    q = pk_horner(q, t, -4.587708865e-01f);
+    q = pk_horner(q, t, -1.151201730e+00f);
+    const f2 e = pk_horner(q, t, -9.999930581e-01f);
+#else
     f2 q = __builtin_elementwise_fma(f2{1.243920691e-07f, 1.243920691e-07f}, t, f2{-3.183690609e-06f, -3.183690609e-06f});
     q = pk_horner(q, t, 3.204980433e-05f);
     q = pk_horner(q, t, -1.323212435e-04f);
@@ -143,6 +164,7 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
     q = pk_horner(q, t, -4.591856045e-01f);
     q = pk_horner(q, t, -1.151105393e+00f);
     const f2 e = pk_horner(q, t, -1.0f);
+#endif
     // the library is built with -mno-amdgpu-ieee -fno-honor-nans: fminf / fmaxf are single v_min / v_max (no canonicalising
     // v_max x, x in front of each)
     return f2{fmaf(-fabsf(x.x), __builtin_amdgcn_exp2f(e.x), fmaxf(x.x, 0.f)), fmaf(-fabsf(x.y), __builtin_amdgcn_exp2f(e.y), fmaxf(x.y, 0.f))};
@@ -150,44 +172,6 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
 __device__ __forceinline__ f4 gelu4(f4 v) {
     const f2 a = gelu2(f2{v.x, v.y}), b = gelu2(f2{v.z, v.w});
     return f4{a.x, a.y, b.x, b.y};
-}
-
-// Table form of the same GELU for the f16x2 per-edge kernels (tools/fit_gelu_lut.py; max abs error 6.3e-7 with 1024 segments):
-//   gelu(x) = max(x, 0) - |x| h(u),  u = min(|x|, 4 sqrt2),  h(u) = 0.5 erfc(u / sqrt2) ~ a[i] + b[i] f,  i = round(u S), f = u S - i.
-// i is read off the mantissa of u S + 2^23, the {a, b} pair comes with ONE ds_read_b64 from an 8 KB table staged in LDS:
-// 8 plain VALU operations per value and no transcendental — the polynomial form above costs ~5 packed Horner steps (4 cycles each
-// on gfx950's 32-wide SIMDs), a quarter-rate v_exp and 4 more operations, and the GELU phases are a third of a per-edge tile.
-// As in gelu2 the last product uses |x| itself so that NaN / inf inputs stay non-finite (fp16 range flag of the f16x2 path).
-#include "tmpnn_gelu_lut.h"
-#ifndef TM_GELU_LUT
-#define TM_GELU_LUT 1      // 0: the polynomial gelu2 in the f16x2 per-edge kernels too (A/B)
-#endif
-#define TM_GELU_LUT_FLOATS (2 * (TM_GELU_LUT_N + 1))
-// cooperative copy of the table into LDS (call before the first barrier of the kernel; 8 KB from L2 once per workgroup)
-template <int NTHREADS>
-__device__ __forceinline__ void gelu_lut_stage(float *s_lut, int tid) {
-    for (int i = tid; i < TM_GELU_LUT_FLOATS / 2; i += NTHREADS)
-        *reinterpret_cast<f2 *>(s_lut + 2 * i) = *reinterpret_cast<const f2 *>(tm_gelu_lut + 2 * i);
-}
-// `lut` = LDS byte address of the staged table (gelu_lut_base), wave-uniform: it rides in an SGPR as the addend of the
-// v_mad_u32_u24 that turns the index into the entry's address (a table above the 64 KB reach of the DS offset field would
-// otherwise cost a v_add per value).
-__device__ __forceinline__ unsigned gelu_lut_base(const float *s_lut) {
-    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float *)s_lut);
-}
-__device__ __forceinline__ float gelu_lut1(float x, unsigned lut) {
-    const float ax = fabsf(x);
-    const float u = fminf(ax, TM_GELU_LUT_U);
-    const float y = __builtin_fmaf(u, TM_GELU_LUT_S, 8388608.0f);            // 2^23 + round(u S): the index sits in the mantissa
-    const float f = __builtin_fmaf(u, TM_GELU_LUT_S, 8388608.0f - y);         // u S - round(u S), in [-0.5, 0.5]
-    unsigned addr;                                                            // the low 24 bits of y's pattern ARE the index
-    asm("v_mad_u32_u24 %0, %1, 8, %2" : "=v"(addr) : "v"(y), "s"(lut));       // (one op; __umul24 is an out-of-line ockl call here)
-    const f2 e = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(addr);
-    const float h = __builtin_fmaf(f, e.y, e.x);
-    return __builtin_fmaf(-ax, h, fmaxf(x, 0.f));
-}
-__device__ __forceinline__ f4 gelu4_lut(f4 v, unsigned lut) {
-    return f4{gelu_lut1(v.x, lut), gelu_lut1(v.y, lut), gelu_lut1(v.z, lut), gelu_lut1(v.w, lut)};
 }
 
 // Weight fragment for one 16-column block: wr[4*kk+s] = W[(n0 + lane&15) * ld + k0 + 16*kk + 4*(lane>>4) + s].

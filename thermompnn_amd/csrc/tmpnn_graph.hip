@@ -412,6 +412,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 1)) void featurize_kernel(F
 // fp32 output tile — are aliased on the dead RBF planes.
 // ------------------------------------------------------------------------------------------------
 #define RBFP_ROWB 1024
+#ifndef TM_ABL_NOGAUSS
+#define TM_ABL_NOGAUSS 0   // timing-only ablation: the Gaussians are not generated (GEMM 1 runs on stale planes)
+#endif
 #ifndef TM_FEAT_PF
 #define TM_FEAT_PF 1      // B-fragment prefetch distance of GEMM 1 (mma_tile_split): 1 = 0.500 ms with 38 spilled VGPRs (reloaded around the GEMM, not in it) against 0.524 at 0 (13 spilled), 0.527 at 2
 #endif
@@ -539,6 +542,9 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
             const int p = tid / (TM_TILE * 2), rem = tid - p * (TM_TILE * 2);
             *reinterpret_cast<u4 *>(rbf + plane_off8<TM_TILE, RBFP_ROWB>(p, rem >> 1, 50 + (rem & 1))) = u4{0u, 0u, 0u, 0u};
         }
+#if TM_ABL_NOGAUSS
+        if (false)
+#endif
         for (int e = tid; e < TM_TILE * 100; e += 512) {        // 16 Gaussians per pair, 4 per thread (:1111-1119)
             const int mm = e / 100, c = e - mm * 100;
             const float D = s_dist[mm][c >> 2];

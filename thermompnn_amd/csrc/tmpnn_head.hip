@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
             if (!ok) { ra = zero4; rb = zero4; }
             bool bad = false;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) bad = bad || tm_nonfinite_bits(ra[k]) || tm_nonfinite_bits(rb[k]);
+            for (int k = 0; k < 4; ++k) bad = bad || tm_f16_range_bits(ra[k]) || tm_f16_range_bits(rb[k]);   // non-finite, or finite but beyond fp16: the planes below could not carry it
             if (a.status && bad) atomicOr(a.status, TMPNN_STATUS_RANGE);
             const f4 va = __builtin_bit_cast(f4, ra), vb = __builtin_bit_cast(f4, rb);
             store_split<SP, ROWS>(pX[0], row, c, va);
@@ -262,8 +262,14 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
                 if (un < 9 || wv < 4) issue(un);
                 mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, 3>(pX[kt], wf, acc, lane);
             }
+            bool ybad = false;   // this kernel's OWN f16x2 operands: an activation (or a weight, via a NaN accumulator) beyond the fp16
+#pragma unroll           // range would come out of the ReLUs below as a finite, wrong ddG
+            for (int rb = 0; rb < NRB; ++rb) {
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) store_split<SP, ROWS>(pY[g], 16 * rb + m, c4, relu4(acc[rb][0]));
+                for (int k = 0; k < 4; ++k) ybad = ybad || tm_f16_range_computed(acc[rb][0][k]);
+                store_split<SP, ROWS>(pY[g], 16 * rb + m, c4, relu4(acc[rb][0]));
+            }
+            if (a.status && ybad) atomicOr(a.status, TMPNN_STATUS_RANGE);
         }
         __syncthreads();
 
@@ -430,6 +436,24 @@ int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *o
     const int64_t blocks = (T + 3) / 4, cap = (int64_t)tm_num_cus() * 8;
     { tm_prof_begin("log_probs", st); log_probs_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Wout_w, w->Wout_b, h, (int)T, out, status); tm_prof_end(st); }
     return tm_check_launch("log_probs");
+}
+
+// A forward that returns hidden states only (no ddG head, no log-probabilities) has no kernel that looks at them: this one does.
+__global__ __launch_bounds__(TM_THREADS) void range_check_kernel(const unsigned *__restrict__ x, int64_t n4, int32_t *__restrict__ status) {
+    typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TM_THREADS) {
+        const uv4 v = reinterpret_cast<const uv4 *>(x)[i];
+        bad = bad || tm_nonfinite_bits(v.x) || tm_nonfinite_bits(v.y) || tm_nonfinite_bits(v.z) || tm_nonfinite_bits(v.w);
+    }
+    if (bad) atomicOr(status, TMPNN_STATUS_RANGE);
+}
+
+int launch_range_check(const float *x, int64_t n, int32_t *status, hipStream_t st) {
+    if (!status || n <= 0) return TMPNN_OK;
+    const int64_t n4 = n / 4, blocks = (n4 + TM_THREADS - 1) / TM_THREADS, cap = (int64_t)tm_num_cus() * 4;     // n is a multiple of 128 here
+    range_check_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(reinterpret_cast<const unsigned *>(x), n4, status);
+    return tm_check_launch("range_check");
 }
 
 int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float *hS, hipStream_t st) {

@@ -98,6 +98,7 @@ int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const 
                 float *z_opt, int32_t *status, hipStream_t st);
 int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, int32_t *status, hipStream_t st);
 int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float *hS, hipStream_t st);
+int launch_range_check(const float *x, int64_t n, int32_t *status, hipStream_t st);   // ORs TMPNN_STATUS_RANGE if any x is inf / NaN
 int launch_prep_tables(tmpnn_weights *w, hipStream_t st);
 
 int launch_clock_probe(int blocks, int iters, unsigned long long *out, float *sink, hipStream_t st);
@@ -127,3 +128,11 @@ const char *tm_find_wimg(const float *base);                                   /
 // arithmetic touches them: tm_nonfinite_bits on integer loads of the same addresses.
 __device__ __forceinline__ bool tm_nonfinite_bits(unsigned b) { return (b & 0x7f800000u) == 0x7f800000u; }
 __device__ __forceinline__ bool tm_nonfinite(float x) { return tm_nonfinite_bits(__float_as_uint(x)); }   // inf only is guaranteed
+// |x| >= 65504 (the largest fp16), inf and NaN included: a value the f16x2 split cannot carry. On raw bits, like the above.
+__device__ __forceinline__ bool tm_f16_range_bits(unsigned b) { return (b & 0x7fffffffu) >= 0x477fe000u; }
+// The same test on a COMPUTED value: the value is laundered through an empty asm first, so that hipcc (-fno-honor-nans) cannot
+// reason "the result of fp arithmetic is never NaN" and fold the NaN half of the integer comparison away.
+__device__ __forceinline__ bool tm_f16_range_computed(float x) {
+    asm volatile("" : "+v"(x));
+    return tm_f16_range_bits(__float_as_uint(x));
+}

@@ -31,6 +31,12 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 #ifndef TM_SPLIT_MIX
 #define TM_SPLIT_MIX 0     // 1: SplitH2::split2 through v_fma_mixlo/hi_f16 (same bits, 3 instead of 5 VALU ops per pair; measured: enc_edge -1 %, dec_msg +2 %, net nil — off)
 #endif
+#ifndef TM_ABL_NOSPLIT
+#define TM_ABL_NOSPLIT 0   // timing-only ablation: SplitH2 writes the high plane only (no residual, low plane = 0)
+#endif
+#ifndef TM_ABL_NOMFMA
+#define TM_ABL_NOMFMA 0    // timing-only ablation: the tile GEMMs issue no MFMA (and, with nothing to feed, no fragment reads)
+#endif
 #define SPLIT_PLANE_BYTES (TM_TILE * TM_H * 2)   // one 48 x 128 plane of 16-bit values: 12288 B
 
 // ------------------------------------------------------------------------------------------------
@@ -80,6 +86,10 @@ struct SplitH2 {
     static __device__ __forceinline__ void split2(f2 x, unsigned (&p)[2]) {
         const h2 h = __builtin_convertvector(x, h2);                        // v_cvt_pk_f16_f32, RNE
         p[0] = __builtin_bit_cast(unsigned, h);
+#if TM_ABL_NOSPLIT
+        p[1] = 0u;
+        return;
+#endif
 #if TM_SPLIT_MIX
         // l = fp16(x - h) per half in ONE mixed-precision fma each (f32 x, f16 h read in place, f16 result written into its
         // half of the destination): 3 VALU ops per pair instead of 5 (two v_cvt_f32_f16, a packed subtract, a packed
@@ -187,6 +197,9 @@ __device__ __forceinline__ void load_wfrag_split(const float *__restrict__ W, in
 template <typename SP, int NK32, int NCB, int NRB = 3, int ROWS = TM_TILE, int ROWB = 256, int NKTOT = NK32, int C0 = 0,
           bool SWZ = true, int PF = 0>
 __device__ __forceinline__ void mma_tile_split(const char *tile, const WFragS<SP> (&w)[NCB][NKTOT], f4 (&acc)[NRB][NCB], int lane) {
+#if TM_ABL_NOMFMA
+    return;
+#endif
     const int m = lane & 15, q = lane >> 4;
     f4 lo[NRB][NCB];
 #pragma unroll

@@ -27,8 +27,17 @@
 #ifndef TM_MSG_TOUCH
 #define TM_MSG_TOUCH 1
 #endif
-#ifndef TM_EDGE_STATS_V2
-#define TM_EDGE_STATS_V2 1   // edge update (f16x2): two-pass partials + 8-lane DPP merge of the LayerNorm statistics (tmpnn_split.h); 0 = the Chan-merge form (A/B)
+// timing-only ablations of the per-edge kernels (wrong results; tools/ablate_build.sh): each removes ONE ingredient so that
+// its true cost in the pipeline shows as a time difference — TM_ABL_NOGELU (tmpnn_common.h), TM_ABL_NOSPLIT / TM_ABL_NOMFMA
+// (tmpnn_split.h), TM_ABL_NOLN (edge update: no LayerNorm statistics)
+#ifndef TM_ABL_NOLN
+#define TM_ABL_NOLN 0
+#endif
+#ifndef TM_ABL_NOLOAD
+#define TM_ABL_NOLOAD 0      // timing-only: the per-edge kernels never fetch the NEXT e tile (they keep re-using the first one)
+#endif
+#ifndef TM_MSG_PFD
+#define TM_MSG_PFD 1         // message kernel: e tiles requested this many tiles ahead of the one in the planes (registers: 12 VGPRs each)
 #endif
 #ifndef TM_MSG_PF
 #define TM_MSG_PF 3      // B-fragment prefetch distance (steps) of the 8-wavefront message kernel GEMMs, see mma_tile_split
@@ -271,20 +280,8 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     __shared__ __attribute__((aligned(16))) char tE[TILEB];
     __shared__ __attribute__((aligned(16))) char tX[TILEB];              // x planes; later the fp32 LayerNorm input
     __shared__ __attribute__((aligned(16))) char tY[TILEB];
-    #if TM_EDGE_STATS_V2
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT_LD];
-#else
-    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
-#endif
     __shared__ int s_idx[2][TM_TILE];
-#if TM_GELU_LUT
-    __shared__ __attribute__((aligned(16))) float s_lut[TM_GELU_LUT_FLOATS];
-    gelu_lut_stage<512>(s_lut, threadIdx.x);            // published by the prologue's first barrier
-    const unsigned lut = gelu_lut_base(s_lut);
-#define TM_GELU4(v) gelu4_lut(v, lut)
-#else
-#define TM_GELU4(v) gelu4(v)
-#endif
     float *tO = reinterpret_cast<float *>(tX);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
@@ -338,8 +335,14 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         {
             if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf2 * TM_KS + tid];
             const float *src = a.hE + (size_t)ipf * TM_KS * TM_H + ncol;
+#if TM_ABL_NOLOAD
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = e_cur[rb];
+            (void)src;
+#else
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = ld4(src + (16 * rb + m) * TM_H);
+#endif
         }
         f4 acc[3][1];
 #pragma unroll
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         {   // the three row blocks' GELUs as six independent chains, then the three splits
             f4 g[3];
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) g[rb] = TM_GELU4(acc[rb][0]);
+            for (int rb = 0; rb < 3; ++rb) g[rb] = gelu4(acc[rb][0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) store_split<SP>(tX, 16 * rb + m, c4, g[rb]);
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         {
             f4 g[3];
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) g[rb] = TM_GELU4(acc[rb][0]);
+            for (int rb = 0; rb < 3; ++rb) g[rb] = gelu4(acc[rb][0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) store_split<SP>(tY, 16 * rb + m, c4, g[rb]);
@@ -389,10 +392,10 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         for (int rb = 0; rb < 3; ++rb) {
             const f4 v = e_cur[rb] + acc[rb][0];                             // residual on the fp32 tile
             st4(tO + chunk_off(16 * rb + m, c4), v);
-            #if TM_EDGE_STATS_V2
-            row_stats_partial16(v, &s_stat[16 * rb + m][2 * wv], q);
+            #if TM_ABL_NOLN
+            (void)q;
 #else
-            row_stats_partial1b(v, &s_stat[16 * rb + m][2 * wv], q);
+            row_stats_partial16(v, &s_stat[16 * rb + m][2 * wv], q);
 #endif
         }
         mark(7);
@@ -410,11 +413,9 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int row = 6 * wv + 2 * it + (lane >> 5);
-            float mean, rstd;
-            #if TM_EDGE_STATS_V2
+            float mean = 0.f, rstd = 1.f;
+#if !TM_ABL_NOLN
             row_stats_finish8d(&s_stat[row][0], lane, mean, rstd);
-#else
-            row_stats_finish8b(&s_stat[row][0], mean, rstd);
 #endif
             const f4 y = (ld4(tO + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
             // rows without a neighbour keep the zeros the featurizer wrote: store zeros again (no divergent branch)
@@ -424,146 +425,6 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         mark(9);
         __syncthreads();
         mark(10);
-    }
-}
-#undef TM_GELU4
-
-// ------------------------------------------------------------------------------------------------
-// Three-barrier form of the edge update (f16x2): the e planes are double-buffered, the fp32 LayerNorm tile no longer aliases
-// the x planes and the neighbour lists rotate through four buffers, so the barrier that closed an iteration is gone — the
-// split of the NEXT tile's rows is written (into the other e buffer) before the barrier that publishes the LayerNorm input,
-// and a wavefront that finishes its LayerNorm rows early starts GEMM 1 of the next tile at once (it touches nothing a
-// wavefront still normalising reads: tO, the statistics, list buffer n & 3). Same arithmetic and per-phase schedule as
-// enc_edge8_rp_kernel; results are bit-identical to it.
-// ------------------------------------------------------------------------------------------------
-template <typename SP>
-__global__ __launch_bounds__(512, 2) void enc_edge8_ob_kernel(EdgeArgsB a) {
-    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
-    __shared__ __attribute__((aligned(16))) char tE[2][TILEB];
-    __shared__ __attribute__((aligned(16))) char tX[TILEB];
-    __shared__ __attribute__((aligned(16))) char tY[TILEB];
-    __shared__ __attribute__((aligned(16))) float tO[TM_TILE * TM_H];    // fp32 LayerNorm input
-    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT_LD];
-    __shared__ int s_idx[4][TM_TILE];
-    __shared__ __attribute__((aligned(16))) float s_lut[TM_GELU_LUT_FLOATS];
-    gelu_lut_stage<512>(s_lut, threadIdx.x);            // published by the prologue's first barrier
-    const unsigned lut = gelu_lut_base(s_lut);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-
-    WFragS<SP> w11[1][4], w12[1][4], w13[1][4];
-    load_wfrag_auto<SP>(a.img11, a.W11e, 384, wv, lane, w11[0]);
-    load_wfrag_auto<SP>(a.img12, a.W12, TM_H, wv, lane, w12[0]);
-    load_wfrag_auto<SP>(a.img13, a.W13, TM_H, wv, lane, w13[0]);
-    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
-    const int c32 = lane & 31;
-    const f4 b12 = ld4(a.b12 + ncol), b13 = ld4(a.b13 + ncol);
-    const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
-
-    const TileRange tr = xcd_tile_range(a.T);
-    int i = tr.begin;
-    const int last = i < tr.end ? i + ((tr.end - 1 - i) / tr.step) * tr.step : i;      // this workgroup's last tile
-    auto tile_at = [&](int k) {                         // k-th tile from the current one, clamped to the last (re-read, never stored twice)
-        const long long t = (long long)i + (long long)k * tr.step;
-        return t < (long long)last ? (int)t : last;
-    };
-    int cur = 0, lb = 0;
-    f4 gai, gcj[3], e_cur[3], e_nxt[3];
-    int nidx = -1;                                      // list entry (thread < 48) of the NEXT tile, requested one iteration early
-    if (i < tr.end) {
-        if (tid < TM_TILE) s_idx[0][tid] = a.E_idx[(size_t)i * TM_KS + tid];
-        const float *src = a.hE + (size_t)i * TM_KS * TM_H + ncol;
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) e_cur[rb] = ld4(src + (16 * rb + m) * TM_H);
-        __syncthreads();
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) store_split<SP>(tE[0], 16 * rb + m, c4, e_cur[rb]);
-        gai = ld4(a.P + (size_t)i * 256 + ncol);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const int j = s_idx[0][16 * rb + m];
-            gcj[rb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol);
-        }
-        touch(gai);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) touch(gcj[rb]);
-        if (tid < TM_TILE) nidx = a.E_idx[(size_t)tile_at(1) * TM_KS + tid];
-        __syncthreads();
-    }
-    for (; i < tr.end; i += tr.step) {
-        float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
-        const int i1 = tile_at(1), i2 = tile_at(2);
-        const int nidx_pub = nidx;                      // list of tile i1, requested during the previous iteration
-        {
-            if (tid < TM_TILE) nidx = a.E_idx[(size_t)i2 * TM_KS + tid];
-            const float *src = a.hE + (size_t)i1 * TM_KS * TM_H + ncol;
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = ld4(src + (16 * rb + m) * TM_H);
-        }
-        f4 acc[3][1];
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
-        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tE[cur], w11, acc, lane);
-        {   // the three row blocks' GELUs as independent chains, then the three splits
-            f4 g[3];
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) g[rb] = gelu4_lut(acc[rb][0], lut);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) store_split<SP>(tX, 16 * rb + m, c4, g[rb]);
-        }
-        if (tid < TM_TILE) s_idx[(lb + 1) & 3][tid] = nidx_pub;
-        __syncthreads();                                // A: tX + the next list complete
-
-        gai = ld4(a.P + (size_t)i1 * 256 + ncol);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const int j = s_idx[(lb + 1) & 3][16 * rb + m];
-            gcj[rb] = ld4(a.P + (size_t)(j < 0 ? i1 : j) * 256 + 128 + ncol);
-        }
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
-        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tX, w12, acc, lane);
-        {
-            f4 g[3];
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) g[rb] = gelu4_lut(acc[rb][0], lut);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) store_split<SP>(tY, 16 * rb + m, c4, g[rb]);
-        }
-        __syncthreads();                                // B: tY complete (every wavefront has left the previous tile's LayerNorm rows)
-
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
-        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tY, w13, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const f4 v = e_cur[rb] + acc[rb][0];                             // residual on the fp32 tile
-            st4(tO + chunk_off(16 * rb + m, c4), v);
-            row_stats_partial16(v, &s_stat[16 * rb + m][2 * wv], q);
-        }
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {                                     // the next tile's planes, into the OTHER e buffer
-            store_split<SP>(tE[cur ^ 1], 16 * rb + m, c4, e_nxt[rb]);
-            e_cur[rb] = e_nxt[rb];
-        }
-        __syncthreads();                                // C: tO + statistics + tE[cur^1] complete
-
-        touch(gai);                                     // the next tile's gathers have long arrived: take their vmcnt wait
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) touch(gcj[rb]); // here, in front of the stores below (see touch())
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int row = 6 * wv + 2 * it + (lane >> 5);
-            float mean, rstd;
-            row_stats_finish8d(&s_stat[row][0], lane, mean, rstd);
-            const f4 y = (ld4(tO + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
-            // rows without a neighbour keep the zeros the featurizer wrote: store zeros again (no divergent branch)
-            st4(tile_g + (size_t)row * TM_H + 4 * c32, s_idx[lb][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
-        }
-        cur ^= 1;
-        lb = (lb + 1) & 3;
-        // no barrier: see the header comment
     }
 }
 
@@ -586,9 +447,7 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
             fprintf(stderr, "enc_edge phases (cycles, wg 0): gemm1 %llu gelu+split %llu bar %llu gather+gemm2 %llu gelu+split %llu bar %llu gemm3 %llu resid+stats %llu bar %llu split+ln+store %llu bar %llu\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
         } else {
-            static const bool ob = [] { const char *e = getenv("TMPNN_EDGE_3BAR"); return e != nullptr && e[0] == '1'; }();
-            if (ob) enc_edge8_ob_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
-            else enc_edge8_rp_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
+            enc_edge8_rp_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
         }
     }
     return tm_check_launch("enc_edge_split");
@@ -753,14 +612,6 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     __shared__ __attribute__((aligned(16))) char tA[TILEB];
     __shared__ int s_idx[2][TM_TILE];
     __shared__ float s_ma[2][TM_TILE];
-#if TM_GELU_LUT
-    __shared__ __attribute__((aligned(16))) float s_lut[TM_GELU_LUT_FLOATS];
-    gelu_lut_stage<512>(s_lut, threadIdx.x);            // published by the prologue's first barrier
-    const unsigned lut = gelu_lut_base(s_lut);
-#define TM_GELU4(v) gelu4_lut(v, lut)
-#else
-#define TM_GELU4(v) gelu4(v)
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
     WFragS<SP> w1[1][4], w2[1][4];
@@ -777,6 +628,9 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         }
     };
     f4 g0, gj[3], e_nxt[3];
+#if TM_MSG_PFD == 2
+    f4 e_far[3];                                       // the tile after e_nxt's
+#endif
     auto gather = [&](int ii, int buf) {
         g0 = ld4(a.P + (size_t)ii * 256 + ncol);
 #pragma unroll
@@ -789,11 +643,12 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     // row layout: one half-wavefront per 512-byte row, fully coalesced (the message kernels never need the tile in
     // the accumulator layout)
     const int prow = 6 * wv + (lane >> 5), pc = lane & 31;
-    auto fetch_tile = [&](int ii) {
+    auto fetch_into = [&](f4 (&dst)[3], int ii) {
         const float *src = a.hE + ((size_t)ii * TM_KS + prow) * TM_H + 4 * pc;
 #pragma unroll
-        for (int it = 0; it < 3; ++it) e_nxt[it] = ld4(src + 2 * it * TM_H);
+        for (int it = 0; it < 3; ++it) dst[it] = ld4(src + 2 * it * TM_H);
     };
+    auto fetch_tile = [&](int ii) { fetch_into(e_nxt, ii); };
     auto split_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < 3; ++it) store_split<SP>(tE, prow + 2 * it, pc, e_nxt[it]);
@@ -812,6 +667,9 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         split_tile();
         gather(i, 0);
         fetch_tile(i + tr.step < tr.end ? i + tr.step : i);     // e_nxt always holds the tile AFTER the one in the planes
+#if TM_MSG_PFD == 2
+        fetch_into(e_far, i + 2 * tr.step < tr.end ? i + 2 * tr.step : i);
+#endif
         __syncthreads();
     }
     mark(-1);
@@ -834,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         for (int rb = 0; rb < 3; ++rb) {
             f4 v = acc[rb][0];
             if (DEC) v = g0 + mi * v;
-            store_split<SP>(tA, 16 * rb + m, c4, TM_GELU4(v));
+            store_split<SP>(tA, 16 * rb + m, c4, gelu4(v));
         }
         if (tid < TM_TILE) {
             s_idx[cur ^ 1][tid] = nidx;
@@ -850,7 +708,14 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         // loads, that wait would also force the tile loads home after one GEMM phase instead of one full iteration (an HBM
         // round trip under load is longer than a phase: ablation showed only 0.02 of the 0.09 ms of e-tile streaming hidden).
         gather(ipf, cur ^ 1);
+#if TM_ABL_NOLOAD
+#elif TM_MSG_PFD == 2
+#pragma unroll
+        for (int it = 0; it < 3; ++it) e_nxt[it] = e_far[it];   // (register renaming: the planes just took e_nxt)
+        fetch_into(e_far, i + 3 * tr.step < tr.end ? i + 3 * tr.step : ipf);
+#else
         fetch_tile(ipf + tr.step < tr.end ? ipf + tr.step : ipf);
+#endif
         mark(3);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = bias2;
@@ -860,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             const float ma = s_ma[cur][16 * rb + m];
-            f4 v = TM_GELU4(acc[rb][0]) * ma;
+            f4 v = gelu4(acc[rb][0]) * ma;
             if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
             tot += v;
         }
@@ -899,153 +764,6 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         mark(7);
     }
 }
-#undef TM_GELU4
-
-// ------------------------------------------------------------------------------------------------
-// One-barrier form of the message kernel (f16x2). Same arithmetic, same per-wavefront schedule inside the phases as
-// msg8_rp_kernel, but the e planes, the activation planes and the neighbour lists are multi-buffered so that ONE workgroup
-// barrier per residue is enough (a barrier costs ~280 cycles even for the last wavefront to arrive):
-//   phase 1 (tile n):  GEMM 1 on tE[c]  ->  GELU -> tA[c];  split tile n+1 (registers) -> tE[c^1];  gather the node terms of
-//                      tile n+1;  request tile n+2;  publish the list of tile n+2              -- barrier --
-//   phase 2 (tile n):  GEMM 2 on tA[c]  ->  GELU, mask, sum over K, store                     (no barrier)
-// A wavefront that runs ahead into phase 1 of tile n+1 writes tA[c^1], tE[c] and list buffer (n+3) & 3 — none of which a
-// wavefront still in phase 2 of tile n reads (tA[c], list buffer n & 3); everything phase 1 of tile n+1 reads was published
-// by the barrier of tile n. Lists are published one tile earlier than in msg8_rp_kernel so that the node-term gathers can be
-// issued BEFORE the request for the tile after next (gfx9 retires loads in order: a wait for the gathers must not drag the
-// tile rows home early).
-// ------------------------------------------------------------------------------------------------
-template <typename SP, bool DEC>
-__global__ __launch_bounds__(512, 2) void msg8_ob_kernel(MsgArgsB a) {
-    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
-    __shared__ __attribute__((aligned(16))) char tE[2][TILEB];
-    __shared__ __attribute__((aligned(16))) char tA[2][TILEB];
-    __shared__ int s_idx[4][TM_TILE];
-    __shared__ float s_ma[4][TM_TILE];
-    __shared__ __attribute__((aligned(16))) float s_lut[TM_GELU_LUT_FLOATS];
-    gelu_lut_stage<512>(s_lut, threadIdx.x);            // published by the prologue's first barrier
-    const unsigned lut = gelu_lut_base(s_lut);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-
-    WFragS<SP> w1[1][4], w2[1][4];
-    load_wfrag_auto<SP>(a.img1, a.W1e, a.ld1, wv, lane, w1[0]);
-    load_wfrag_auto<SP>(a.img2, a.W2, TM_H, wv, lane, w2[0]);
-    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
-    const f4 bias2 = ld4(a.b2 + ncol);
-
-    f4 g0, gj[3], e_nxt[3];
-    auto gather = [&](int ii, int buf) {
-        g0 = ld4(a.P + (size_t)ii * 256 + ncol);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const int j0 = s_idx[buf][16 * rb + m];
-            const int j = j0 < 0 ? ii : j0;
-            gj[rb] = ld4(a.P + (size_t)j * 256 + 128 + ncol);
-        }
-    };
-    const int prow = 6 * wv + (lane >> 5), pc = lane & 31;          // row layout: one half-wavefront per 512-byte row
-    auto fetch_tile = [&](int ii) {
-        const float *src = a.hE + ((size_t)ii * TM_KS + prow) * TM_H + 4 * pc;
-#pragma unroll
-        for (int it = 0; it < 3; ++it) e_nxt[it] = ld4(src + 2 * it * TM_H);
-    };
-    auto split_tile = [&](char *dst) {
-#pragma unroll
-        for (int it = 0; it < 3; ++it) store_split<SP>(dst, prow + 2 * it, pc, e_nxt[it]);
-    };
-
-    const TileRange tr = xcd_tile_range(a.T);
-    int i = tr.begin;
-    const int last = i < tr.end ? i + ((tr.end - 1 - i) / tr.step) * tr.step : i;      // this workgroup's last tile
-    auto tile_at = [&](int k) {                         // index of the k-th tile from the current one, clamped to the last
-        const long long t = (long long)i + (long long)k * tr.step;
-        return t < (long long)last ? (int)t : last;
-    };
-    int cur = 0, lb = 0;                                // plane buffer / list buffer of the current tile
-    int nidx = -1;                                      // list entry (thread < 48) of the tile two ahead: requested one iteration early
-    if (i < tr.end) {
-        const int i1 = tile_at(1);
-        if (tid < TM_TILE) {
-            const int j0 = a.E_idx[(size_t)i * TM_KS + tid], j1 = a.E_idx[(size_t)i1 * TM_KS + tid];
-            s_idx[0][tid] = j0;
-            s_ma[0][tid] = j0 < 0 ? 0.f : (DEC ? 1.f : a.mask[i] * a.mask[j0]);
-            s_idx[1][tid] = j1;
-            s_ma[1][tid] = j1 < 0 ? 0.f : (DEC ? 1.f : a.mask[i1] * a.mask[j1]);
-            nidx = a.E_idx[(size_t)tile_at(2) * TM_KS + tid];
-        }
-        fetch_tile(i);
-        __syncthreads();
-        split_tile(tE[0]);
-        gather(i, 0);
-        fetch_tile(i1);                                 // e_nxt always holds the tile AFTER the one in the planes
-        __syncthreads();
-    }
-    for (; i < tr.end; i += tr.step) {
-        const int i1 = tile_at(1), i2 = tile_at(2), i3 = tile_at(3);
-        const float mi = a.mask[i];
-        float nma = 0.f;                                // mask of the list two ahead (its indices arrived an iteration ago)
-        if (tid < TM_TILE && nidx >= 0) nma = DEC ? 1.f : a.mask[i2] * a.mask[nidx];
-        f4 acc[3][1];
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
-        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tE[cur], w1, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            f4 v = acc[rb][0];
-            if (DEC) v = g0 + mi * v;
-            store_split<SP>(tA[cur], 16 * rb + m, c4, gelu4_lut(v, lut));
-        }
-        split_tile(tE[cur ^ 1]);                        // tile n+1: requested during phase 1 of the previous iteration
-        gather(i1, (lb + 1) & 3);                       // its list was published by the previous barrier
-        fetch_tile(i2);
-        if (tid < TM_TILE) {
-            s_idx[(lb + 2) & 3][tid] = nidx;
-            s_ma[(lb + 2) & 3][tid] = nma;
-            nidx = a.E_idx[(size_t)i3 * TM_KS + tid];
-        }
-        __syncthreads();                                // tA[cur], tE[cur^1], list (lb+2)&3 complete
-
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = bias2;
-        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tA[cur], w2, acc, lane);
-        f4 tot = f4{0.f, 0.f, 0.f, 0.f};                // masked sum over the K neighbours, in registers
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const float ma = s_ma[lb][16 * rb + m];
-            f4 v = gelu4_lut(acc[rb][0], lut) * ma;
-            if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
-            tot += v;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {                    // inclusive scan over the 16 rows of the lane group (DPP row_shr,
-            float x = tot[c];                           // zero fill): lane m = 15 ends up with the column sum
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xf, 0xf, true));
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, true));
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xf, 0xf, true));
-            tot[c] = x;
-        }
-        touch(g0);                                      // take the gathers' vmcnt wait before any store is issued (see touch())
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) touch(gj[rb]);
-        if (m == 15) st4(a.Ssum + (size_t)i * TM_H + ncol, tot);
-        if (wv == 2) {                                  // neighbour count of this tile: one wavefront-wide DPP sum
-            float c = lane < TM_TILE ? s_ma[lb][lane] : 0.f;
-#define TM_DPP_ADD(ctrl, row_mask, bc)                                                                  \
-            c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), ctrl, row_mask, 0xf, bc));
-            TM_DPP_ADD(0x111, 0xf, true)
-            TM_DPP_ADD(0x112, 0xf, true)
-            TM_DPP_ADD(0x114, 0xf, true)
-            TM_DPP_ADD(0x118, 0xf, true)                // lane 15 of every row: the row's sum
-            TM_DPP_ADD(0x142, 0xa, false)               // row_bcast:15 into rows 1 and 3
-            TM_DPP_ADD(0x143, 0xc, false)               // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-#undef TM_DPP_ADD
-            if (lane == 63) a.cnt[i] = c;
-        }
-        cur ^= 1;
-        lb = (lb + 1) & 3;
-    }
-}
-
 
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                      const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt,
@@ -1068,14 +786,8 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
             (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
             fprintf(stderr, "dec_msg phases (cycles, wg 0): fetch+gemm1 %llu gelu+split %llu bar %llu split_tile+gather %llu gemm2 %llu gelu+mask %llu bar %llu ksum+store %llu\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-        } else {
-            static const bool onebar = [] { const char *e = getenv("TMPNN_MSG_ONEBAR"); return e != nullptr && e[0] == '1'; }();
-            if (onebar) {
-                if (dec) msg8_ob_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
-                else msg8_ob_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
-            } else if (dec) msg8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
-            else msg8_rp_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
-        }
+        } else if (dec) msg8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
+        else msg8_rp_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
     }
     return tm_check_launch(dec ? "dec_msg_split" : "enc_msg_split");
 }

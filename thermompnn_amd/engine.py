@@ -33,8 +33,8 @@ class Weights:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device, with_head: Optional[bool] = None,
                  precision: Optional[str] = None, tensors: Optional[List[torch.Tensor]] = None):
         """``precision``: "f16x2" | "bf16x3" | "fp32" (matrix-core path of every call through this handle) or None for
-        the library default. ``tensors``: device tensors of another Weights of the same model to share (a second
-        handle at another precision costs only its 0.8 MB of derived tables)."""
+        the library default. ``tensors``: device tensors of another Weights of the same model to share (a second handle
+        costs only its derived data: 0.8 MB of tables, plus 7.2 MB of f16 fragment images for an "f16x2" handle)."""
         lib = _lib.load()
         if precision is not None and precision not in _lib.PRECISIONS:
             raise TmpnnError(f"precision={precision!r}: expected one of {_lib.PRECISIONS}")
@@ -59,7 +59,8 @@ class Weights:
             self.tensors.append(t)
         self.device = device
         self.with_head = with_head
-        self.packed = torch.empty(lib.tmpnn_weights_packed_bytes(), dtype=torch.uint8, device=device)
+        self.packed = torch.empty(lib.tmpnn_weights_packed_bytes_p(precision.encode() if precision else None), dtype=torch.uint8,
+                                  device=device)
         arr = (C.c_void_p * n)(*[t.data_ptr() for t in self.tensors])
         self.handle = C.c_void_p()
         with torch.cuda.device(device):

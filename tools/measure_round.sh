@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that refreshes every artefact under profiles/ for round $1 (e.g. r02). Run on the GPU box:
-#   tools/measure_round.sh r02        -> gpurun_out/$1_*  (copy into profiles/ afterwards)
-R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r02}; O=$R/gpurun_out
+#   tools/measure_round.sh r03        -> gpurun_out/$1_*  (copy into profiles/ afterwards)
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r03}; O=$R/gpurun_out
 mkdir -p $O
 cd $R
 bash tools/pmc_traffic.sh > $O/${TAG}_pmc_traffic.log 2>&1
@@ -12,7 +12,11 @@ python tools/run_configs.py > $O/${TAG}_configs_2to5.json 2> $O/${TAG}_configs.e
 ( cd /tmp && export TMPDIR=/tmp && rm -rf $O/prof_$TAG && \
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 10 --warmup 3 --no-extras > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err )
 cp $(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv 2>/dev/null
+# the same trace restricted to the 10 timed steps (the --stats CSV also averages the clock warm-up launches)
+python tools/rocprof_timed_stats.py $(find $O/prof_$TAG -name "*kernel_trace.csv" | head -1) 10 > $O/${TAG}_bench_kernel_stats_timed.csv
+python bench.py --scaling strong --steps 20 --warmup 5 > $O/${TAG}_bench_strong_1gpu.json 2> $O/${TAG}_bench_strong.err
+TMPNN_BENCH_ONE_DEVICE=1 TMPNN_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --proteins-per-gpu 8 --no-cpu-baseline > $O/${TAG}_bench_selflaunch_2ranks_one_device.json 2> $O/${TAG}_bench_selflaunch.err
 bash tools/pmc_sq.sh > $O/${TAG}_pmc_sq.log 2>&1
 cp $O/pmc_sq_summary.txt $O/${TAG}_pmc_sq_summary.txt
 rm -rf $O/prof_$TAG/*/*.db 2>/dev/null
-tail -c 600 $O/${TAG}_bench_full.err; head -c 400 $O/${TAG}_bench_full.json; echo; head -5 $O/${TAG}_bench_kernel_stats.csv; tail -12 $O/${TAG}_pmc_traffic.log
+tail -c 600 $O/${TAG}_bench_full.err; head -c 400 $O/${TAG}_bench_full.json; echo; head -9 $O/${TAG}_bench_kernel_stats_timed.csv; tail -12 $O/${TAG}_pmc_traffic.log

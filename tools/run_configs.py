@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import fetch_profile, kernel_flops  # noqa: E402
+from bench import fetch_profile, kernel_bytes, kernel_flops, kernel_roofs  # noqa: E402
 from thermompnn_amd import _lib  # noqa: E402
 from thermompnn_amd.engine import Engine  # noqa: E402
 from thermompnn_amd.synthetic import synthetic_backbone  # noqa: E402
@@ -88,8 +88,15 @@ res["config4_megascale_like"] = {"proteins": 300, "residues": b["T"], "mutations
 b = pack([2048], [3])
 dt, k = run(b, 50, 5)
 res["config5_L2048"] = {"ms": dt * 1e3, "preds_per_s": 40960 / dt, "kernel_avg_ms": k,
+                        # per kernel: algorithmic HBM bytes / launch time, and the fraction of its binding roof (bench.kernel_roofs)
+                        "kernel_hbm_GBps": {n: kernel_bytes(n, 2048, 2048 * 48) / (v * 1e-3) / 1e9 for n, v in k.items() if kernel_bytes(n, 2048, 2048 * 48)},
+                        "kernel_roofs": {n: {kk: r[kk] for kk in ("bound", "frac", "t_hbm_us", "t_mfma_us")}
+                                         for n, v in k.items() if kernel_bytes(n, 2048, 2048 * 48)
+                                         for r in [kernel_roofs(n, 2048, 2048 * 48, v, eng.precision)]},
+                        "note": "one 2048-residue chain = 2048 tiles on 256 CUs: 8 tiles per persistent workgroup, so prologues (weight fragments) "
+                                "and the tail weigh more than in the 64-protein batch; k-NN rows > 512 use the LDS form",
                         # default (f16x2) kernels, from hipcc -Rpass-analysis=kernel-resource-usage
                         "lds_bytes_per_workgroup": {"knn (4 rows)": 4 * (2048 + 33) * 4, "featurize_split": 135232, "msg8_rp": 49920,
-                                                    "enc_edge8_rp": 77184, "node_update8 (64 rows)": 98304, "head8 (48 rows)": 147648},
+                                                    "enc_edge8_rp": 77568, "node_update8 (64 rows)": 98304, "head8 (48 rows)": 147648},
                         "waves_per_simd": {"knn": 8, "featurize_split": 2, "msg8_rp": 2, "enc_edge8_rp": 2, "node_update8": 2, "head8": 2}}
 print(json.dumps(res, indent=1))
