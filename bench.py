@@ -203,6 +203,26 @@ def gather_microbench(eng, device, n_nodes=16384, K=48, C_=128, iters=20):
             "measured_copy_GBps": copy_gbs}
 
 
+def usable_cpus():
+    """Logical CPUs this process may actually use: the scheduler affinity mask, capped by the cgroup CPU quota (a container
+    that shows 256 CPUs in /proc/cpuinfo may be allowed a fraction of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return n, quota
+
+
 def host_cpu_info():
     model = None
     try:
@@ -212,7 +232,8 @@ def host_cpu_info():
                 break
     except OSError:
         pass
-    return {"host_cpus": os.cpu_count(), "cpu_model": model}
+    aff, quota = usable_cpus()
+    return {"host_cpus": os.cpu_count(), "cpu_model": model, "affinity_cpus": aff, "cgroup_cpu_quota": quota}
 
 
 def cpu_baseline_reference_shaped(batch, threads, budget_s=8.0):
@@ -316,7 +337,8 @@ def cpu_baseline_saturated(threads_per_proc=8, window_s=10.0, startup_s=25.0):
     """Throughput-fair CPU leg: P = host_cpus / 8 processes x 8 threads, every one running the oracle's vectorised SSM of
     one L=256 protein for the same wall-clock window; aggregate preds/s over the window (repetitions that END inside it)."""
     import subprocess
-    ncpu = os.cpu_count() or 8
+    aff, quota = usable_cpus()
+    ncpu = int(min(aff, quota)) if quota else aff        # what the container may really use
     P = max(1, ncpu // threads_per_proc)
     t_start = time.time() + startup_s                    # the P interpreters import torch and warm up before the window opens
     t_end = t_start + window_s
@@ -334,7 +356,7 @@ def cpu_baseline_saturated(threads_per_proc=8, window_s=10.0, startup_s=25.0):
             failed += 1
             pr.kill()
     return {"value": reps * 5120 / window_s, "unit": "preds/s", "processes": P, "threads": threads_per_proc,
-            "cores": P * threads_per_proc, "failed_processes": failed, "late_processes": late, "window_s": window_s,
+            "cores": P * threads_per_proc, "usable_cpus": ncpu, "failed_processes": failed, "late_processes": late, "window_s": window_s,
             "sample": f"{P} processes x {threads_per_proc} threads, each repeating the vectorised full SSM of one synthetic L=256 "
                       f"protein (5120 preds) for a common {window_s:.0f} s window: {reps} completed"}
 

@@ -945,7 +945,7 @@ def test_range_flag_covers_the_head_and_hidden_only_forwards(synthetic_weights):
         warnings.simplefilter("always")
         got = Engine(W, "cuda:0", 48, precision="f16x2").ssm_forward(*args)["ddg"]          # reruns in bf16x3
     assert any("bf16x3" in str(w.message) for w in rec)
-    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-5 * float(want.abs().max()))   # values ~1e6: fp32 noise
     # a decoder weight: the poisoned state is caught at the head's input
     W2 = {k: v.clone() for k, v in synthetic_weights.items()}
     W2["prot_mpnn.decoder_layers.2.W1.weight"] = W2["prot_mpnn.decoder_layers.2.W1.weight"] * 1e7

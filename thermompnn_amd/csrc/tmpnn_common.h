@@ -29,13 +29,31 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Workgroup / thread indices straight from the hardware registers. The library is built with -mno-amdgpu-ieee, and hipcc then
+// refuses to inline the ockl helpers that sit behind blockIdx / threadIdx / gridDim (the callee's FP-mode attributes differ): every
+// kernel called them through s_swappc and — worse — treated the returned values as DIVERGENT, so the tile index, every per-tile
+// address and every loop bound lived in VGPRs and was recomputed with 64-bit VALU arithmetic (round 3: 3 calls per kernel, 20-30
+// VALU instructions per tile in the per-edge kernels). These read the same values the inlined helpers would: SGPRs, and for
+// gridDim / blockDim the hidden kernel arguments of code-object v5 (hidden_block_count_x at byte 0, hidden_group_size_x at byte 12
+// of the implicit-argument block — device memory, already in the scalar cache with the explicit arguments). NOT
+// __builtin_amdgcn_grid_size_x(): that one reads the AQL dispatch packet, which lives in host memory (measured: +0.25 ms on a
+// 19-launch single-protein forward).
+__device__ __forceinline__ int tm_bid() { return (int)__builtin_amdgcn_workgroup_id_x(); }
+__device__ __forceinline__ int tm_tid() { return (int)__builtin_amdgcn_workitem_id_x(); }
+__device__ __forceinline__ int tm_nblk() {
+    return (int)((const __attribute__((address_space(4))) unsigned *)__builtin_amdgcn_implicitarg_ptr())[0];
+}
+__device__ __forceinline__ int tm_bdim() {
+    return (int)((const __attribute__((address_space(4))) unsigned short *)__builtin_amdgcn_implicitarg_ptr())[6];
+}
+
 // Persistent-kernel work split that is XCD-aware: workgroup b is observed to run on XCD b % 8 (placement is a
 // speed hint only, never relied on for correctness). Giving each XCD one CONTIGUOUS eighth of the packed
 // residue axis keeps the rows its tiles gather (neighbours live in the same protein) inside that XCD's 4 MB L2
 // instead of bouncing the whole [T,256] projection table through every L2 (MI355X_MICROARCH.md: per-XCD L2).
 struct TileRange { int begin, end, step; };
 __device__ __forceinline__ TileRange xcd_tile_range(int n_tiles) {
-    const int G = gridDim.x, b = blockIdx.x;
+    const int G = tm_nblk(), b = tm_bid();
     if ((G & 7) == 0 && n_tiles >= 8 * G) {
         const int x = b & 7, lb = b >> 3;
         const int s = (int)((long long)n_tiles * x / 8), e = (int)((long long)n_tiles * (x + 1) / 8);

@@ -211,10 +211,10 @@ __global__ __launch_bounds__(TM_THREADS, NS == 8 ? 4 : 8) void knn_kernel(const 
                                                             int K, int32_t *__restrict__ E_idx, float *__restrict__ D_nb,
                                                             int32_t *__restrict__ status, KnnInit init) {
     extern __shared__ __attribute__((aligned(16))) float knn_lds[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = tm_tid() & 63, wv = tm_tid() >> 6;
     float *d = knn_lds + (size_t)wv * (max_len + (max_len >> 6) + 1);
 
-    for (int i = blockIdx.x * 4 + wv; i < T; i += gridDim.x * 4) {
+    for (int i = tm_bid() * 4 + wv; i < T; i += tm_nblk() * 4) {
         if (init.hV0) {      // the fused forward: this residue's all-zero initial state and its projection (W . 0 + b = b exactly)
             const f4 z = f4{0.f, 0.f, 0.f, 0.f};
             if (lane < 32) st4(init.hV0 + (size_t)i * TM_H + 4 * lane, z);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 1)) void featurize_kernel(F
     __shared__ float s_dist[TM_TILE][28];
     __shared__ int s_idx[TM_TILE];
     __shared__ int s_dpos[TM_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31;
     const int col0 = (TM_H / NW) * wv, chunk0 = (32 / NW) * wv;
 
@@ -423,7 +423,7 @@ template <typename SP, bool PROF = false, bool IMG = false>
 __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, unsigned long long *prof = nullptr) {
     unsigned long long t_last = 0;
     auto mark = [&](int k) {
-        if (PROF && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (PROF && tm_bid() == 0 && tm_tid() == 0) {
             const unsigned long long t = __builtin_readcyclecounter();
             if (k >= 0) prof[k] += t - t_last;
             t_last = t;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
     __shared__ int s_idx[2][TM_TILE];
     __shared__ int s_dpos[2][TM_TILE];
     char *tAp = rbf;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31;
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
 
@@ -620,12 +620,12 @@ __global__ __launch_bounds__(TM_THREADS) void gather_rows_kernel(const float *__
     const int64_t total = n_rows * C4;
     // XCD-aware split (see xcd_tile_range): each XCD streams one contiguous eighth of the output, so the table
     // rows it gathers (neighbours are local) stay in its own L2
-    int64_t g0 = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x, g1 = total, stride = (int64_t)gridDim.x * TM_THREADS;
-    if ((gridDim.x & 7) == 0 && total >= 8 * stride) {
-        const int x = blockIdx.x & 7;
+    int64_t g0 = (int64_t)tm_bid() * TM_THREADS + tm_tid(), g1 = total, stride = (int64_t)tm_nblk() * TM_THREADS;
+    if ((tm_nblk() & 7) == 0 && total >= 8 * stride) {
+        const int x = tm_bid() & 7;
         const int64_t s = total / 8 * x;
         g1 = x == 7 ? total : total / 8 * (x + 1);
-        g0 = s + (int64_t)(blockIdx.x >> 3) * TM_THREADS + threadIdx.x;
+        g0 = s + (int64_t)(tm_bid() >> 3) * TM_THREADS + tm_tid();
         stride >>= 3;
     }
     for (int64_t g = g0; g < g1; g += stride) {
@@ -648,8 +648,8 @@ __global__ __launch_bounds__(TM_THREADS) void gather_rows_scalar_kernel(const fl
                                                                         int64_t rows_per_batch, int64_t nodes_per_batch,
                                                                         int C, float *__restrict__ out) {
     const int64_t total = n_rows * C;
-    const int64_t stride = (int64_t)gridDim.x * TM_THREADS;
-    for (int64_t g = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x; g < total; g += stride) {
+    const int64_t stride = (int64_t)tm_nblk() * TM_THREADS;
+    for (int64_t g = (int64_t)tm_bid() * TM_THREADS + tm_tid(); g < total; g += stride) {
         const int64_t r = g / C;
         const int c = (int)(g - r * C);
         const int64_t j = (int64_t)idx[r];
@@ -663,8 +663,8 @@ __global__ __launch_bounds__(TM_THREADS) void gather_edges_kernel(const float *_
                                                                   const int64_t *__restrict__ idx, int64_t n_rows,
                                                                   int N, int K, int C, float *__restrict__ out) {
     const int64_t total = n_rows * C;
-    const int64_t stride = (int64_t)gridDim.x * TM_THREADS;
-    for (int64_t g = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x; g < total; g += stride) {
+    const int64_t stride = (int64_t)tm_nblk() * TM_THREADS;
+    for (int64_t g = (int64_t)tm_bid() * TM_THREADS + tm_tid(); g < total; g += stride) {
         const int64_t r = g / C;            // r = (b*N + i)*K + k
         const int c = (int)(g - r * C);
         const int64_t bi = r / K;
@@ -678,8 +678,8 @@ __global__ __launch_bounds__(TM_THREADS) void gather_edges_kernel(const float *_
 __global__ __launch_bounds__(TM_THREADS) void centrality_kernel(const float *__restrict__ X, const float *__restrict__ mask,
                                                                 const int32_t *__restrict__ offsets, int N, int T,
                                                                 float radius, int32_t *__restrict__ out) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = blockIdx.x * 4 + wv; i < T; i += gridDim.x * 4) {
+    const int lane = tm_tid() & 63, wv = tm_tid() >> 6;
+    for (int i = tm_bid() * 4 + wv; i < T; i += tm_nblk() * 4) {
         int lo = 0, hi = N;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;

@@ -32,11 +32,11 @@ __global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
     __shared__ __attribute__((aligned(16))) float tX[3][ROWS * TM_H];
     __shared__ __attribute__((aligned(16))) float tY[3][ROWS * TM_H];
     __shared__ int s_S[ROWS];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int n_tiles = (a.T + ROWS - 1) / ROWS;
     const float dw = a.ddg_w[0], db = a.ddg_b[0];
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = tm_bid(); tile < n_tiles; tile += tm_nblk()) {
         const int r0 = tile * ROWS, rows = min(ROWS, a.T - r0);
         if (tid < ROWS) s_S[tid] = tid < rows ? a.S[r0 + tid] : 0;
         load_tile<NRB>(tX[0], a.hA + (size_t)r0 * TM_H, rows, tid);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
     __shared__ __attribute__((aligned(16))) char pY[3][PLT];
     __shared__ int s_S[ROWS];
     float *tF0 = reinterpret_cast<float *>(pX[0]), *tF1 = reinterpret_cast<float *>(pX[1]), *tF2 = reinterpret_cast<float *>(pX[2]);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
     const int n_tiles = (a.T + ROWS - 1) / ROWS;
     const float dw = a.ddg_w[0], db = a.ddg_b[0];
@@ -220,9 +220,9 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
     load_wfrag<4>(a.w2, 64, 16 * (wv & 1), 0, 32, w32[0], lane);
     load_wfrag<2>(a.w3, 32, 16 * (wv & 1), 0, TMPNN_VOCAB, w8[0], lane);
 
-    int tile = blockIdx.x;
+    int tile = tm_bid();
     if (tile < n_tiles) issue(0);
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (; tile < n_tiles; tile += tm_nblk()) {
         const int r0 = tile * ROWS, rows = min(ROWS, a.T - r0);
         if (tid < ROWS) s_S[tid] = tid < rows ? a.S[r0 + tid] : 0;
         for (int idx = tid; idx < ROWS * 32; idx += 512) {      // x = [h_last | h_prev | W_s[S]] -> planes
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) st4(tF0 + chunk_off(16 * rb + m, c4), relu4(acc[rb][0]));
         }
-        if (tile + (int)gridDim.x < n_tiles) issue(0);          // unit 0 of this workgroup's next tile
+        if (tile + (int)tm_nblk() < n_tiles) issue(0);          // unit 0 of this workgroup's next tile
         __syncthreads();
         if (wv < 2) {   // 64 -> 32, relu -> tF1[:, 0:32]
             f4 acc[NRB][1];
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
 __global__ __launch_bounds__(TM_THREADS) void log_probs_kernel(const float *__restrict__ W, const float *__restrict__ b,
                                                                const float *__restrict__ h, int T,
                                                                float *__restrict__ out, int32_t *__restrict__ status) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int t = blockIdx.x * 4 + wv; t < T; t += gridDim.x * 4) {
+    const int lane = tm_tid() & 63, wv = tm_tid() >> 6;
+    for (int t = tm_bid() * 4 + wv; t < T; t += tm_nblk() * 4) {
         float logit = -INFINITY;
         if (status) {      // poisoned input row -> flag (raw-bit test on the loaded values, see tm_nonfinite_bits)
             const unsigned *ur = reinterpret_cast<const unsigned *>(h + (size_t)t * TM_H);
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(TM_THREADS) void log_probs_kernel(const float *__re
 
 __global__ __launch_bounds__(TM_THREADS) void seq_embed_kernel(const float *__restrict__ Ws, const int32_t *__restrict__ S,
                                                                int64_t T, float *__restrict__ hS) {
-    const int64_t total = T * 32, stride = (int64_t)gridDim.x * TM_THREADS;
-    for (int64_t g = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x; g < total; g += stride) {
+    const int64_t total = T * 32, stride = (int64_t)tm_nblk() * TM_THREADS;
+    for (int64_t g = (int64_t)tm_bid() * TM_THREADS + tm_tid(); g < total; g += stride) {
         const int64_t t = g >> 5;
         const int c = (int)(g & 31);
         st4(hS + g * 4, ld4(Ws + S[t] * TM_H + 4 * c));
@@ -365,20 +365,20 @@ __global__ __launch_bounds__(TM_THREADS) void seq_embed_kernel(const float *__re
 // derived tables, computed once per weight set
 __global__ void prep_pos_table_kernel(const float *__restrict__ pos_w, const float *__restrict__ pos_b,
                                       const float *__restrict__ edge_w, float *__restrict__ table) {
-    const int d = blockIdx.x, n = threadIdx.x;     // 66 x 128
+    const int d = tm_bid(), n = tm_tid();     // 66 x 128
     float s = 0.f;
     for (int p = 0; p < 16; ++p) s += (pos_w[p * 66 + d] + pos_b[p]) * edge_w[n * 416 + p];
     table[d * TM_H + n] = s;
 }
 __global__ void prep_seq_table_kernel(const float *__restrict__ Ws, const float *__restrict__ W1,
                                       float *__restrict__ table) {
-    const int s = blockIdx.x, n = threadIdx.x;     // 21 x 128;  W1 [128,512], columns 256..383 multiply W_s[S_j]
+    const int s = tm_bid(), n = tm_tid();     // 21 x 128;  W1 [128,512], columns 256..383 multiply W_s[S_j]
     float acc = 0.f;
     for (int k = 0; k < TM_H; ++k) acc += Ws[s * TM_H + k] * W1[n * 512 + 256 + k];
     table[s * TM_H + n] = acc;
 }
 __global__ void prep_conv_center_kernel(const float *__restrict__ conv_w, float *__restrict__ center) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 384*384
+    const int i = tm_bid() * tm_bdim() + tm_tid();   // 384*384
     if (i < 384 * 384) center[i] = conv_w[(size_t)i * 9 + 4];
 }
 
@@ -442,7 +442,7 @@ int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *o
 __global__ __launch_bounds__(TM_THREADS) void range_check_kernel(const unsigned *__restrict__ x, int64_t n4, int32_t *__restrict__ status) {
     typedef unsigned uv4 __attribute__((ext_vector_type(4)));
     bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * TM_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TM_THREADS) {
+    for (int64_t i = (int64_t)tm_bid() * TM_THREADS + tm_tid(); i < n4; i += (int64_t)tm_nblk() * TM_THREADS) {
         const uv4 v = reinterpret_cast<const uv4 *>(x)[i];
         bad = bad || tm_nonfinite_bits(v.x) || tm_nonfinite_bits(v.y) || tm_nonfinite_bits(v.z) || tm_nonfinite_bits(v.w);
     }

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_proj_kernel(const float *_
                                                                   const float *__restrict__ add_tab,
                                                                   const int32_t *__restrict__ add_idx) {
     __shared__ __attribute__((aligned(16))) float tA[TM_TILE * TM_H];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     float wa[2][32], wc[2][32];
     f4 bias[2];
 #pragma unroll
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_proj_kernel(const float *_
         bias[cb] = ld4(ba + n0 + 4 * q);
     }
     const int n_tiles = (T + TM_TILE - 1) / TM_TILE;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = tm_bid(); tile < n_tiles; tile += tm_nblk()) {
         const int r0 = tile * TM_TILE;
         load_tile(tA, h + (size_t)r0 * TM_H, min(TM_TILE, T - r0), tid);
         __syncthreads();
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void msg_kernel(MsgArgs a) {
     __shared__ float s_part[3][TM_H];
     __shared__ int s_idx[TM_TILE];
     __shared__ float s_ma[TM_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int col0 = (TM_H / NW) * wv, chunk0 = (32 / NW) * wv;
 
     float w1[NCB][32], w2[NCB][32];
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
     __shared__ int s_idx[2][TM_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
     float w11[1][32], w12[1][32], w13[1][32];
     load_wfrag<8>(a.W11e, 384, 16 * wv, 0, TM_H, w11[0], lane);
@@ -350,11 +350,11 @@ __global__ __launch_bounds__(TM_THREADS, 2) void node_update_kernel(NodeArgs a) 
     constexpr int ROWS = 16 * NRB;
     __shared__ __attribute__((aligned(16))) float tA[ROWS * TM_H];
     __shared__ __attribute__((aligned(16))) float tB[ROWS * TM_H];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31;
     const int n_tiles = (a.T + ROWS - 1) / ROWS;
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = tm_bid(); tile < n_tiles; tile += tm_nblk()) {
         const int r0 = tile * ROWS;
         load_tile<NRB>(tA, a.Ssum + (size_t)r0 * TM_H, min(ROWS, a.T - r0), tid);
         __syncthreads();
@@ -571,7 +571,7 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TM_THREADS, 1) void clock_probe_kernel(int iters, unsigned long long *out, float *sink) {
     __shared__ __attribute__((aligned(16))) float tile[TM_TILE * TM_H];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = tm_tid(), lane = tid & 63;
     for (int k = tid; k < TM_TILE * TM_H; k += TM_THREADS) tile[k] = 1e-3f * (float)(k & 255);
     float w[2][32];
 #pragma unroll
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void clock_probe_kernel(int iters, u
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) sum += acc[rb][cb].x + acc[rb][cb].w;
     if (sum == 123.456f) sink[tid] = sum;
-    if (tid == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = t1 - t0; }
+    if (tid == 0) { out[2 * tm_bid()] = c1 - c0; out[2 * tm_bid() + 1] = t1 - t0; }
 }
 
 int launch_clock_probe(int blocks, int iters, unsigned long long *out, float *sink, hipStream_t st) {

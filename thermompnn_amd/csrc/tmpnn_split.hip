@@ -54,12 +54,12 @@ __global__ __launch_bounds__(512, 2) void gemm_probe_kernel(const float *__restr
     __shared__ __attribute__((aligned(16))) float tF[TM_TILE * TM_H];
     using SP = typename std::conditional<MODE == 2, SplitH2, SplitBF3>::type;
     __shared__ __attribute__((aligned(16))) char tP[3 * SPLIT_PLANE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     float wf[1][32];
     WFragS<SP> w3[1][4];
     if (MODE == 0) load_wfrag<8>(W, TM_H, 16 * wv, 0, TM_H, wf[0], lane);
     else load_wfrag_split<SP, 4>(W, TM_H, 16 * wv, 0, TM_H, w3[0], lane);
-    for (int i = blockIdx.x; i < T; i += gridDim.x) {
+    for (int i = tm_bid(); i < T; i += tm_nblk()) {
         const float *src = X + (size_t)i * TM_TILE * TM_H;
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_split_kernel(EdgeArgsB a) {
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
     __shared__ int s_idx[2][TM_TILE];
     float *tO = reinterpret_cast<float *>(tX);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
     WFragS<SP> w11[1][4], w12[1][4], w13[1][4];
     load_wfrag_split<SP, 4>(a.W11e, 384, 16 * wv, 0, TM_H, w11[0], lane);
@@ -265,11 +265,12 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_split_kernel(EdgeArgsB a) {
 // next iteration. No LDS staging, no LDS-DMA (whose conservative vmcnt(0) waits serialised the store phase), biases and
 // LayerNorm parameters live in registers, every global access of the loop is unconditional.
 // ------------------------------------------------------------------------------------------------
-template <typename SP, bool PROF = false>
+// OFF32: see msg8_rp_kernel (32-bit gather offsets when the projection table is smaller than 4 GB).
+template <typename SP, bool PROF = false, bool OFF32 = false>
 __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsigned long long *prof = nullptr) {
     unsigned long long t_last = 0;
     auto mark = [&](int k) {           // TMPNN_EDGE_PROF=1: phase timing of thread 0 of workgroup 0
-        if (PROF && blockIdx.x == 0 && threadIdx.x == TM_PROF_TID) {
+        if (PROF && tm_bid() == 0 && tm_tid() == TM_PROF_TID) {
             const unsigned long long t = __builtin_readcyclecounter();
             if (k >= 0) prof[k] += t - t_last;
             t_last = t;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT_LD];
     __shared__ int s_idx[2][TM_TILE];
     float *tO = reinterpret_cast<float *>(tX);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
     WFragS<SP> w11[1][4], w12[1][4], w13[1][4];
     load_wfrag_auto<SP>(a.img11, a.W11e, 384, wv, lane, w11[0]);
@@ -291,11 +292,19 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     load_wfrag_auto<SP>(a.img13, a.W13, TM_H, wv, lane, w13[0]);
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
     const int c32 = lane & 31;
+    const unsigned ucol = (unsigned)ncol;
+    const unsigned eoff = (unsigned)(m * TM_H + ncol);                    // this thread's offset inside an e tile (accumulator layout, row block 0)
+    const unsigned soff = (unsigned)((6 * wv + (lane >> 5)) * TM_H + 4 * c32);   // ... in the row layout of the LayerNorm / store phase
+    auto prow_of = [&](int j, int self) -> const float * {                // &P[j][128 + ncol] (j < 0: the residue's own row)
+        const int jj = j < 0 ? self : j;
+        if constexpr (OFF32) return a.P + ((unsigned)jj * 256u + (128u + ucol));
+        else return a.P + (size_t)jj * 256 + 128 + ncol;
+    };
     const f4 b12 = ld4(a.b12 + ncol), b13 = ld4(a.b13 + ncol);
     const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
 
 #if TM_SETPRIO
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);    // (provably wave-uniform condition: s_setprio ignores EXEC)
+    if (__builtin_amdgcn_readfirstlane(tm_tid()) >= 256) __builtin_amdgcn_s_setprio(1);    // (provably wave-uniform condition: s_setprio ignores EXEC)
 #endif
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin;
@@ -303,18 +312,15 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     f4 gai, gcj[3], e_cur[3], e_nxt[3];
     if (i < tr.end) {
         if (tid < TM_TILE) s_idx[0][tid] = a.E_idx[(size_t)i * TM_KS + tid];
-        const float *src = a.hE + (size_t)i * TM_KS * TM_H + ncol;
+        const float *src = a.hE + (size_t)i * TM_KS * TM_H;
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) e_cur[rb] = ld4(src + (16 * rb + m) * TM_H);
+        for (int rb = 0; rb < 3; ++rb) e_cur[rb] = ld4(src + (eoff + 16 * rb * TM_H));
         __syncthreads();
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) store_split<SP>(tE, 16 * rb + m, c4, e_cur[rb]);
-        gai = ld4(a.P + (size_t)i * 256 + ncol);
+        gai = ld4(a.P + (size_t)i * 256 + ucol);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const int j = s_idx[0][16 * rb + m];
-            gcj[rb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol);
-        }
+        for (int rb = 0; rb < 3; ++rb) gcj[rb] = ld4(prow_of(s_idx[0][16 * rb + m], i));
         touch(gai);                                    // (so that the loop header needs no vmcnt wait of its own)
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) touch(gcj[rb]);
@@ -334,14 +340,14 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         const int nidx_pub = nidx;                         // list of tile ipf, requested during the previous iteration
         {
             if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf2 * TM_KS + tid];
-            const float *src = a.hE + (size_t)ipf * TM_KS * TM_H + ncol;
+            const float *src = a.hE + (size_t)ipf * TM_KS * TM_H;         // wave-uniform base + per-thread offset
 #if TM_ABL_NOLOAD
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = e_cur[rb];
             (void)src;
 #else
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = ld4(src + (16 * rb + m) * TM_H);
+            for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = ld4(src + (eoff + 16 * rb * TM_H));
 #endif
         }
         f4 acc[3][1];
@@ -362,12 +368,9 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         __syncthreads();
         mark(2);
 
-        gai = ld4(a.P + (size_t)ipf * 256 + ncol);
+        gai = ld4(a.P + (size_t)ipf * 256 + ucol);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const int j = s_idx[cur ^ 1][16 * rb + m];
-            gcj[rb] = ld4(a.P + (size_t)(j < 0 ? ipf : j) * 256 + 128 + ncol);
-        }
+        for (int rb = 0; rb < 3; ++rb) gcj[rb] = ld4(prow_of(s_idx[cur ^ 1][16 * rb + m], ipf));
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
         mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tX, w12, acc, lane);
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
 #endif
             const f4 y = (ld4(tO + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
             // rows without a neighbour keep the zeros the featurizer wrote: store zeros again (no divergent branch)
-            st4(tile_g + (size_t)row * TM_H + 4 * c32, s_idx[cur][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
+            st4(tile_g + (soff + 2 * it * TM_H), s_idx[cur][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
         }
         cur ^= 1;
         mark(9);
@@ -441,11 +444,13 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
             static unsigned long long *d_prof = nullptr;
             if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
             (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
-            enc_edge8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a, d_prof);
+            enc_edge8_rp_kernel<SplitH2, true, false><<<grid, 512, 0, st>>>(a, d_prof);
             unsigned long long h[16];
             (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
             fprintf(stderr, "enc_edge phases (cycles, wg 0): gemm1 %llu gelu+split %llu bar %llu gather+gemm2 %llu gelu+split %llu bar %llu gemm3 %llu resid+stats %llu bar %llu split+ln+store %llu bar %llu\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+        } else if (T < ((int64_t)1 << 22)) {
+            enc_edge8_rp_kernel<SplitH2, false, true><<<grid, 512, 0, st>>>(a);      // projection table < 4 GB: 32-bit gather offsets
         } else {
             enc_edge8_rp_kernel<SplitH2><<<grid, 512, 0, st>>>(a);
         }
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void msg8_split_kernel(MsgArgsB a) {
     __shared__ float s_part[3][TM_H];
     __shared__ int s_idx[2][TM_TILE];
     __shared__ float s_ma[2][TM_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
     WFragS<SP> w1[1][4], w2[1][4];
     load_wfrag_split<SP, 4>(a.W1e, a.ld1, 16 * wv, 0, TM_H, w1[0], lane);
@@ -597,11 +602,14 @@ __global__ __launch_bounds__(512, 2) void msg8_split_kernel(MsgArgsB a) {
 
 // Register-prefetch form of the message kernel (f16x2): the next residue's fp32 tile is loaded in the accumulator
 // layout at the top of the iteration and split into the e planes once GEMM 1 has consumed the current ones.
-template <typename SP, bool DEC, bool PROF = false>
+// OFF32: the node-projection table is smaller than 4 GB (T < 2^22 rows), so a gathered row is addressed as the uniform table
+// pointer + a 32-bit per-lane byte offset (one VALU op per gather instead of a 64-bit shift + add chain); every other global access
+// of the loop is a wave-uniform base + a per-thread offset computed once, whatever T is.
+template <typename SP, bool DEC, bool PROF = false, bool OFF32 = false>
 __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned long long *prof = nullptr) {
     unsigned long long t_last = 0;
     auto mark = [&](int k) {           // TMPNN_MSG_PROF=1: phase timing of thread 0 of workgroup 0
-        if (PROF && blockIdx.x == 0 && threadIdx.x == TM_PROF_TID) {
+        if (PROF && tm_bid() == 0 && tm_tid() == TM_PROF_TID) {
             const unsigned long long t = __builtin_readcyclecounter();
             if (k >= 0) prof[k] += t - t_last;
             t_last = t;
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     __shared__ __attribute__((aligned(16))) char tA[TILEB];
     __shared__ int s_idx[2][TM_TILE];
     __shared__ float s_ma[2][TM_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
     WFragS<SP> w1[1][4], w2[1][4];
     load_wfrag_auto<SP>(a.img1, a.W1e, a.ld1, wv, lane, w1[0]);
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
 
     auto stage_idx = [&](int ii, int buf) {           // neighbour list + attention mask of residue ii -> LDS
         if (tid < TM_TILE) {
-            const int j = a.E_idx[(size_t)ii * TM_KS + tid];
+            const int j = (a.E_idx + (size_t)__builtin_amdgcn_readfirstlane(ii) * TM_KS)[(unsigned)tid];
             s_idx[buf][tid] = j;
             s_ma[buf][tid] = j < 0 ? 0.f : (DEC ? 1.f : a.mask[ii] * a.mask[j]);
         }
@@ -631,22 +639,25 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
 #if TM_MSG_PFD == 2
     f4 e_far[3];                                       // the tile after e_nxt's
 #endif
+    const unsigned ucol = (unsigned)ncol;
     auto gather = [&](int ii, int buf) {
-        g0 = ld4(a.P + (size_t)ii * 256 + ncol);
+        g0 = ld4(a.P + (size_t)__builtin_amdgcn_readfirstlane(ii) * 256 + ucol);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             const int j0 = s_idx[buf][16 * rb + m];
             const int j = j0 < 0 ? ii : j0;
-            gj[rb] = ld4(a.P + (size_t)j * 256 + 128 + ncol);
+            if constexpr (OFF32) gj[rb] = ld4(a.P + ((unsigned)j * 256u + (128u + ucol)));
+            else gj[rb] = ld4(a.P + (size_t)j * 256 + 128 + ncol);
         }
     };
     // row layout: one half-wavefront per 512-byte row, fully coalesced (the message kernels never need the tile in
     // the accumulator layout)
     const int prow = 6 * wv + (lane >> 5), pc = lane & 31;
+    const unsigned eoff = (unsigned)(prow * TM_H + 4 * pc);         // this thread's offset inside any e tile
     auto fetch_into = [&](f4 (&dst)[3], int ii) {
-        const float *src = a.hE + ((size_t)ii * TM_KS + prow) * TM_H + 4 * pc;
+        const float *src = a.hE + (size_t)__builtin_amdgcn_readfirstlane(ii) * (TM_KS * TM_H);      // wave-uniform: scalar base + lane offset
 #pragma unroll
-        for (int it = 0; it < 3; ++it) dst[it] = ld4(src + 2 * it * TM_H);
+        for (int it = 0; it < 3; ++it) dst[it] = ld4(src + (eoff + 2 * it * TM_H));
     };
     auto fetch_tile = [&](int ii) { fetch_into(e_nxt, ii); };
     auto split_tile = [&]() {
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     };
 
 #if TM_SETPRIO
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+    if (__builtin_amdgcn_readfirstlane(tm_tid()) >= 256) __builtin_amdgcn_s_setprio(1);
 #endif
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin;
@@ -680,14 +691,14 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         // neighbour list of the next residue: loaded first, its dependent mask gather issued behind GEMM 1, both
         // published to LDS only after the epilogue — no wavefront ever sits on a global-load latency in front of its MFMAs
         int nidx = -1;
-        if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf * TM_KS + tid];
+        if (tid < TM_TILE) nidx = (a.E_idx + (size_t)__builtin_amdgcn_readfirstlane(ipf) * TM_KS)[(unsigned)tid];
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
         mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tE, w1, acc, lane);
         mark(0);
         float nma = 0.f;
-        if (tid < TM_TILE && nidx >= 0) nma = DEC ? 1.f : a.mask[ipf] * a.mask[nidx];
+        if (tid < TM_TILE && nidx >= 0) nma = DEC ? 1.f : a.mask[ipf] * a.mask[(unsigned)nidx];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             f4 v = acc[rb][0];
@@ -743,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) touch(gj[rb]);
         }
-        if (m == 15) st4(a.Ssum + (size_t)i * TM_H + ncol, tot);
+        if (m == 15) st4(a.Ssum + (size_t)__builtin_amdgcn_readfirstlane(i) * TM_H + ucol, tot);
         if (wv == 2) {                                           // neighbour count of this tile (read before s_ma[cur] is recycled):
             float c = lane < TM_TILE ? s_ma[cur][lane] : 0.f;    // one wavefront-wide DPP sum (a serial 48-term loop in one lane
 #define TM_DPP_ADD(ctrl, row_mask, bc)                                                                  \
@@ -781,11 +792,14 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
             static unsigned long long *d_prof = nullptr;
             if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
             (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
-            msg8_rp_kernel<SplitH2, true, true><<<grid, 512, 0, st>>>(a, d_prof);
+            msg8_rp_kernel<SplitH2, true, true, false><<<grid, 512, 0, st>>>(a, d_prof);
             unsigned long long h[16];
             (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
             fprintf(stderr, "dec_msg phases (cycles, wg 0): fetch+gemm1 %llu gelu+split %llu bar %llu split_tile+gather %llu gemm2 %llu gelu+mask %llu bar %llu ksum+store %llu\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        } else if (T < ((int64_t)1 << 22)) {           // projection table < 4 GB: 32-bit gather offsets
+            if (dec) msg8_rp_kernel<SplitH2, true, false, true><<<grid, 512, 0, st>>>(a);
+            else msg8_rp_kernel<SplitH2, false, false, true><<<grid, 512, 0, st>>>(a);
         } else if (dec) msg8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);
         else msg8_rp_kernel<SplitH2, false><<<grid, 512, 0, st>>>(a);
     }
@@ -802,7 +816,7 @@ template <typename SP, int NRB, bool IMG, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, unsigned long long *prof = nullptr) {
     int n_mark = 0;
     auto mark = [&]() {                 // TMPNN_NODE_PROF=1: cycle stamps of thread 0 of workgroup 0 at every stage boundary (first tile)
-        if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && n_mark < 32) prof[n_mark++] = __builtin_readcyclecounter();
+        if (PROF && tm_bid() == 0 && tm_tid() == 0 && n_mark < 32) prof[n_mark++] = __builtin_readcyclecounter();
     };
     mark();
     constexpr int ROWS = 16 * NRB, PLT = SP::NP * ROWS * 256;
@@ -821,7 +835,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
     __shared__ float s_cnt[ROWS], s_mask[ROWS];
     __shared__ int s_aidx[2][ROWS];
     float *tA = reinterpret_cast<float *>(pA);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31, hw = tid >> 5;                  // half-wavefront index: rows hw*NRB .. hw*NRB + NRB - 1
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
     const int n_tiles = (a.T + ROWS - 1) / ROWS;
@@ -885,7 +899,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
     };
     const int first_proj = has0 ? 9 : 11;                       // first projection unit, if any
 
-    int tile = blockIdx.x;
+    int tile = tm_bid();
     if (tile >= n_tiles) return;
     {   // every load unconditional and requested before the first LDS write (a load under a branch is waited for at the join:
         // written the obvious way this block was seven dependent round trips, 9 k cycles)
@@ -926,7 +940,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
     }
     mark();
     issue(0);
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (; tile < n_tiles; tile += tm_nblk()) {
         const int r0 = tile * ROWS;
         {   // aggregated messages -> planes, old state -> tB: all 2 NRB row chunks of this thread requested before the first is used
             static_assert(ROWS * 32 == 512 * NRB, "one 16-byte chunk of NRB rows per thread");
@@ -1017,7 +1031,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
             split_raw();                        // W_out chunk c
             if (c < 3) issue(3 + 2 * c);
             else if (has0 || has1) issue(first_proj);
-            else if (tile + (int)gridDim.x < n_tiles) issue(0);
+            else if (tile + (int)tm_nblk() < n_tiles) issue(0);
             mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pA, wf, out, lane);
             __syncthreads();
             mark();
@@ -1052,7 +1066,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
                 // next unit: the C half, the other projection, or W3 of this workgroup's next tile
                 if (!half) issue(10 + 2 * k);
                 else if (k == 0 && has1) issue(11);
-                else if (tile + (int)gridDim.x < n_tiles) issue(0);
+                else if (tile + (int)tm_nblk() < n_tiles) issue(0);
                 {
                     const f4 b = half ? f4{0.f, 0.f, 0.f, 0.f} : ld4(s_par + P_BA + 128 * k + ncol);
 #pragma unroll
@@ -1096,7 +1110,7 @@ __global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsi
     using SP = SplitH2;
     int n_mark = 0;
     auto mark = [&]() {                 // TMPNN_NODE_PROF=1: cycle stamps of thread 0 of workgroup 0 at every stage boundary
-        if (PROF && blockIdx.x == 0 && threadIdx.x == TM_PROF_TID) prof[n_mark++] = __builtin_readcyclecounter();
+        if (PROF && tm_bid() == 0 && tm_tid() == TM_PROF_TID) prof[n_mark++] = __builtin_readcyclecounter();
     };
     mark();
     kernarg_warm<sizeof(NodeArgs)>();
@@ -1106,10 +1120,10 @@ __global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsi
     __shared__ __attribute__((aligned(16))) char pB[PLT];
     __shared__ __attribute__((aligned(16))) float tB[ROWS * TM_H];
     float *tA = reinterpret_cast<float *>(pA);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31, hw = tid >> 5;                  // half-wavefront hw owns row hw in the row phases
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
-    const int r0 = blockIdx.x * ROWS;                           // the launcher starts exactly ceil(T / 16) workgroups
+    const int r0 = tm_bid() * ROWS;                           // the launcher starts exactly ceil(T / 16) workgroups
     // The launcher compacts the projections (the NPROJ present ones first, their images in img[9..]): every kernel argument
     // is then read at a fixed offset and the scalar loads form one cluster (a dependent second round trip to the freshly
     // written argument buffer costs ~0.5 us).
@@ -1240,7 +1254,7 @@ __global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsi
 
 // fragment image of one 128 x 128 block (see WImg in tmpnn_internal.h): [wv 8][c 4][plane 2][lane 64] x 16 B
 __global__ void prep_wimg_kernel(const float *__restrict__ W, int ld, int n_rows, int k_valid, char *__restrict__ dst) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (wv, c, lane)
+    const int idx = tm_bid() * tm_bdim() + tm_tid();      // (wv, c, lane)
     if (idx >= 8 * 4 * 64) return;
     const int lane = idx & 63, c = (idx >> 6) & 3, wv = idx >> 8, m = lane & 15, q = lane >> 4;
     const float *src = W + (size_t)(16 * wv + m) * ld + 32 * c + 8 * q;
