@@ -461,18 +461,30 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-        # proof of what the group is: an all_reduce of ones (on device memory for RCCL) and every rank's device identity
-        ones = torch.ones(1, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(ones)
-        props = torch.cuda.get_device_properties(device)
-        ident = {"rank": rank, "device_index": dev_index, "name": props.name,
-                 "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
-        idents = [None] * world
-        dist.all_gather_object(idents, ident)
+        # the contract is ONE line on stdout: whatever the communication libraries print while they connect (gloo announces its
+        # peers on stdout from C++) goes to stderr — file descriptor 1 points at stderr until the group stands
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
+            # proof of what the group is: an all_reduce of ones (on device memory for RCCL) and every rank's device identity
+            ones = torch.ones(1, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(ones)
+            props = torch.cuda.get_device_properties(device)
+            ident = {"rank": rank, "device_index": dev_index, "name": props.name,
+                     "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
+            idents = [None] * world
+            dist.all_gather_object(idents, ident)
+            if backend == "nccl":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         collective = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world_size": dist.get_world_size(),
                       "ranks_seen": int(ones.item()), "devices": idents,
                       "distinct_devices": len({(d["device_index"], d["uuid"], d["pci_bus_id"]) for d in idents}),

@@ -831,8 +831,8 @@ def _bench(args, env=None, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, env=dict(os.environ, **(env or {})),
                        capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # ONE line on stdout, nothing else (library chatter -> stderr)
     return json.loads(lines[0])
 
 

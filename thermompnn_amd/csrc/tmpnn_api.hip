@@ -222,11 +222,11 @@ extern "C" int tmpnn_weights_create(tmpnn_weights_t **out, const float *const *t
 
 extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const *tensors, int n_tensors, void *packed,
                                       size_t packed_bytes, const char *precision, tmpnn_stream_t stream) {
-    if (!out || !tensors || !packed) return tm_set_error(TMPNN_E_INVALID, "weights_create: null argument");
     const int mode = precision ? parse_mode(precision) : default_mode();
-    if (mode < 0)
+    if (mode < 0)                  // first: a caller that sized `packed` with tmpnn_weights_packed_bytes_p() got 0 for this name
         return tm_set_error(TMPNN_E_INVALID, "weights_create: unknown precision '%s' (f16x2 | bf16x3 | fp32)",
                             precision ? precision : getenv("TMPNN_PRECISION"));
+    if (!out || !tensors || !packed) return tm_set_error(TMPNN_E_INVALID, "weights_create: null argument");
     if (tensor_table().size() != TMPNN_N_TENSORS) return tm_set_error(TMPNN_E_INVALID, "internal tensor table size");
     if (n_tensors != TMPNN_N_MPNN_TENSORS && n_tensors != TMPNN_N_TENSORS)
         return tm_set_error(TMPNN_E_INVALID, "weights_create: n_tensors must be %d or %d, got %d", TMPNN_N_MPNN_TENSORS,

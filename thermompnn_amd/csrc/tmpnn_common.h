@@ -40,6 +40,9 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
 // 19-launch single-protein forward).
 __device__ __forceinline__ int tm_bid() { return (int)__builtin_amdgcn_workgroup_id_x(); }
 __device__ __forceinline__ int tm_tid() { return (int)__builtin_amdgcn_workitem_id_x(); }
+// wavefront index inside the (1-D) workgroup as a SCALAR: tid >> 6 is wave-uniform, but only readfirstlane tells the compiler so —
+// with it the per-wavefront row / column bases, tile pointers and loop bounds are SALU work and scalar loads
+__device__ __forceinline__ int tm_wave(int tid) { return __builtin_amdgcn_readfirstlane(tid >> 6); }
 __device__ __forceinline__ int tm_nblk() {
     return (int)((const __attribute__((address_space(4))) unsigned *)__builtin_amdgcn_implicitarg_ptr())[0];
 }

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(TM_THREADS, NS == 8 ? 4 : 8) void knn_kernel(const 
                                                             int K, int32_t *__restrict__ E_idx, float *__restrict__ D_nb,
                                                             int32_t *__restrict__ status, KnnInit init) {
     extern __shared__ __attribute__((aligned(16))) float knn_lds[];
-    const int lane = tm_tid() & 63, wv = tm_tid() >> 6;
+    const int lane = tm_tid() & 63, wv = tm_wave(tm_tid());
     float *d = knn_lds + (size_t)wv * (max_len + (max_len >> 6) + 1);
 
     for (int i = tm_bid() * 4 + wv; i < T; i += tm_nblk() * 4) {
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(TM_THREADS) void gather_edges_kernel(const float *_
 __global__ __launch_bounds__(TM_THREADS) void centrality_kernel(const float *__restrict__ X, const float *__restrict__ mask,
                                                                 const int32_t *__restrict__ offsets, int N, int T,
                                                                 float radius, int32_t *__restrict__ out) {
-    const int lane = tm_tid() & 63, wv = tm_tid() >> 6;
+    const int lane = tm_tid() & 63, wv = tm_wave(tm_tid());
     for (int i = tm_bid() * 4 + wv; i < T; i += tm_nblk() * 4) {
         int lo = 0, hi = N;
         while (hi - lo > 1) {

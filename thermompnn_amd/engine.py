@@ -59,8 +59,8 @@ class Weights:
             self.tensors.append(t)
         self.device = device
         self.with_head = with_head
-        self.packed = torch.empty(lib.tmpnn_weights_packed_bytes_p(precision.encode() if precision else None), dtype=torch.uint8,
-                                  device=device)
+        nbytes = lib.tmpnn_weights_packed_bytes_p(precision.encode() if precision else None) or lib.tmpnn_weights_packed_bytes()
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)      # (0 = unknown name: create_p reports it)
         arr = (C.c_void_p * n)(*[t.data_ptr() for t in self.tensors])
         self.handle = C.c_void_p()
         with torch.cuda.device(device):
