@@ -420,7 +420,13 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
 #if !TM_ABL_NOLN
             row_stats_finish8d(&s_stat[row][0], lane, mean, rstd);
 #endif
-            const f4 y = (ld4(tO + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
+            // (x - mean) rstd g + be as y = x s + t with s = rstd g, t = be - mean s: three packed fmas / muls per half row
+            const f4 x4 = ld4(tO + chunk_off(row, c32));
+            const f2 s01 = f2{g4.x, g4.y} * rstd, s23 = f2{g4.z, g4.w} * rstd;
+            const f2 t01 = __builtin_elementwise_fma(f2{-mean, -mean}, s01, f2{be4.x, be4.y});
+            const f2 t23 = __builtin_elementwise_fma(f2{-mean, -mean}, s23, f2{be4.z, be4.w});
+            const f2 y01 = __builtin_elementwise_fma(f2{x4.x, x4.y}, s01, t01), y23 = __builtin_elementwise_fma(f2{x4.z, x4.w}, s23, t23);
+            const f4 y = f4{y01.x, y01.y, y23.x, y23.y};
             // rows without a neighbour keep the zeros the featurizer wrote: store zeros again (no divergent branch)
             st4(tile_g + (soff + 2 * it * TM_H), s_idx[cur][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
         }
@@ -734,11 +740,10 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         mark(4);
         f4 tot = f4{0.f, 0.f, 0.f, 0.f};                         // masked sum over the K neighbours, in registers
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const float ma = s_ma[cur][16 * rb + m];
-            f4 v = gelu4(acc[rb][0]) * ma;
-            if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
-            tot += v;
+        for (int rb = 0; rb < 3; ++rb) {                         // tot += ma * gelu(...): one fma per value. (ma is 0 or 1, so the
+            const float ma = s_ma[cur][16 * rb + m];            // product is exact and this IS the reference's mask_attend * h_message,
+            const f4 g = gelu4(acc[rb][0]);                      // :821-823 — a separate "select 0 where ma == 0" cost 5 more VALU per row block)
+            tot = f4{__builtin_fmaf(g.x, ma, tot.x), __builtin_fmaf(g.y, ma, tot.y), __builtin_fmaf(g.z, ma, tot.z), __builtin_fmaf(g.w, ma, tot.w)};
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                             // inclusive scan over the 16 rows of the lane group (DPP row_shr,
