@@ -442,6 +442,12 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ["TMPNN_BENCH_WATCHDOG"]), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)                           # does not return
+    # The contract is ONE line on stdout. The libraries underneath do not know that: RCCL prints a version banner through C stdio
+    # (it surfaces when the process exits), gloo announces its peers while connecting. File descriptor 1 therefore points at stderr
+    # from here to the end of the process; the JSON line is written to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -451,6 +457,10 @@ def main():
     # cuda:0, collectives staged through gloo). The real multi-GPU run uses one GPU per rank over RCCL.
     one_device = os.environ.get("TMPNN_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("TMPNN_BENCH_BACKEND", "nccl")
+    # TMPNN_BENCH_FORCE_GROUP=1: a process group (and the per-step exchange) even with ONE rank — the only way to run RCCL itself
+    # on a 1-GPU box: init_process_group("nccl"), all_reduce / all_gather_into_tensor on device buffers, the asynchronous
+    # double-buffered overlap (a 1-rank ncclAllGather is a device copy, but every call of the N > 1 path is made)
+    grouped = world > 1 or os.environ.get("TMPNN_BENCH_FORCE_GROUP") == "1"
     dev_index = 0 if one_device else local_rank
     if world > 1 and not one_device and torch.cuda.device_count() < world:
         raise SystemExit(f"--gpus {world}: only {torch.cuda.device_count()} GPU(s) visible (one process per GPU)")
@@ -458,33 +468,28 @@ def main():
     device = torch.device("cuda", dev_index)
     dist = None
     collective = None
-    if world > 1:
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the contract is ONE line on stdout: whatever the communication libraries print while they connect (gloo announces its
-        # peers on stdout from C++) goes to stderr — file descriptor 1 points at stderr until the group stands
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=device)
-            else:
-                dist.init_process_group(backend)
-            # proof of what the group is: an all_reduce of ones (on device memory for RCCL) and every rank's device identity
-            ones = torch.ones(1, device=device if backend == "nccl" else "cpu")
-            dist.all_reduce(ones)
-            props = torch.cuda.get_device_properties(device)
-            ident = {"rank": rank, "device_index": dev_index, "name": props.name,
-                     "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
-            idents = [None] * world
-            dist.all_gather_object(idents, ident)
-            if backend == "nccl":
-                torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
+        if world == 1 and "MASTER_PORT" not in os.environ:      # forced 1-rank group without a launcher
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+        # proof of what the group is: an all_reduce of ones (on device memory for RCCL) and every rank's device identity
+        ones = torch.ones(1, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        props = torch.cuda.get_device_properties(device)
+        ident = {"rank": rank, "device_index": dev_index, "name": props.name,
+                 "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
         collective = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world_size": dist.get_world_size(),
                       "ranks_seen": int(ones.item()), "devices": idents,
                       "distinct_devices": len({(d["device_index"], d["uuid"], d["pci_bus_id"]) for d in idents}),
@@ -506,18 +511,18 @@ def main():
     # N > 1: the per-step exchange (all-gather of the ddG tables over RCCL/xGMI) is asynchronous and double-buffered: the
     # collective of step k runs on RCCL's stream under the forward of step k+1; a buffer pair is reused only after its
     # collective has been waited for (stream-side wait, no host sync). Everything is drained inside the timed region.
-    nbuf = 2 if world > 1 else 1
+    nbuf = 2 if grouped else 1
     outs = [{"ddg": torch.zeros((gather_rows_n, 21), dtype=torch.float32, device=device)} for _ in range(nbuf)]
     views = [{"ddg": o["ddg"][:T_loc]} for o in outs]     # the forward writes the first T_loc rows; the padding stays zero
     out = views[0]
-    gathered = [torch.empty((world * gather_rows_n, 21), dtype=torch.float32, device=device) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world * gather_rows_n, 21), dtype=torch.float32, device=device) for _ in range(2)] if grouped else None
     picked = [None]
     pending = [None, None]
     step_no = [0]
 
     def step(gather=True):
-        k = step_no[0] & 1 if world > 1 else 0
-        if world > 1 and pending[k] is not None:
+        k = step_no[0] & 1 if grouped else 0
+        if grouped and pending[k] is not None:
             pending[k].wait()
             pending[k] = None
             if strong:
@@ -525,7 +530,7 @@ def main():
         # check_status=False: nothing in the step synchronises; the device status word is read once after the timed region
         eng.ssm_forward(batch["X"], batch["S"], batch["mask"], batch["ridx"], batch["cenc"], batch["offsets"],
                         max_len=max_len, out=views[k], check_status=False)
-        if world == 1:
+        if not grouped:
             if strong:
                 picked[0] = outs[0]["ddg"].view(-1)[sw["sel"]]
         elif not gather:
@@ -551,7 +556,7 @@ def main():
 
     def barrier():
         drain()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -582,7 +587,7 @@ def main():
         dt_ = time.perf_counter() - t0
         prof_ = fetch_profile(lib) if profile else {}
         lib.tmpnn_profile_enable(0)
-        if world > 1:
+        if grouped:
             tmax = torch.tensor([dt_], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_ = float(tmax.item())
@@ -602,7 +607,7 @@ def main():
         units_per_step, unit_name = world * B * L * 20, "mutant ddG predictions"
         workload = (f"BASELINE configs[1] x {B}: {B} synthetic L={L} proteins per GPU (K=48, h=128), full 20xL SSM each, inputs "
                     "resident in HBM" + ("; per-step RCCL all-gather of ddG tables (asynchronous, overlapped with the next step)"
-                                         if world > 1 else ""))
+                                         if grouped else ""))
     result = {
         "metric": "mutant ddG preds/sec (SSM, L=256, K=48)", "value": units_per_step * args.steps / dt, "unit": "preds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -624,7 +629,7 @@ def main():
         result["collective"] = collective
     if strong:
         result["table_preds_per_s"] = 20 * sw["total_T"] * args.steps / dt
-        if world > 1:                                    # the same steps without the exchange (and without the selection)
+        if grouped:                                      # the same steps without the exchange (and without the selection)
             for _ in range(2):
                 step(gather=False)
             barrier()
@@ -708,7 +713,7 @@ def main():
         lat = latency(fwd1)
         result["single_protein"] = {"ms": lat * 1e3, "preds_per_s": L * 20 / lat}
         try:
-            if world > 1:     # no stream capture next to a live RCCL communicator (its watchdog thread's event queries can invalidate one)
+            if grouped:       # no stream capture next to a live RCCL communicator (its watchdog thread's event queries can invalidate one)
                 raise RuntimeError("hipGraph leg skipped in multi-rank runs; measured in the 1-GPU run")
             graph, _ = eng.capture_graph(one["X"], one["S"], one["mask"], one["ridx"], one["cenc"], one["offsets"], max_len=L, out=o1)
             ref = o1["ddg"].clone()
@@ -727,7 +732,7 @@ def main():
         except Exception as e:                                # graph capture is an extra: report, do not fail the line
             result["single_protein"]["hipgraph_error"] = repr(e)[:300]
         # the other matrix-core paths on the SAME workload, same process (precision is an engine argument)
-        if world == 1:
+        if not grouped:
             modes = {}
             for prec in ("f16x2", "bf16x3", "fp32"):
                 if prec == eng.precision:
@@ -756,7 +761,7 @@ def main():
                                "enc_edge_bound": r2["bound"] if r2 else None,
                                "enc_edge_frac_of_binding_roof": r2["frac"] if r2 else None}
             result["modes"] = modes
-        if world == 1 and not args.no_cpu_baseline:
+        if not grouped and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(batch)
             try:
                 sat = cpu_baseline_saturated()
@@ -769,8 +774,8 @@ def main():
             result["cpu_baseline"]["gpu_over_cpu_note"] = ("against the saturated host (all logical CPUs busy)" if sat.get("value")
                                                            else "against the best single-process thread count")
     if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+        os.write(out_fd, (json.dumps(result) + "\n").encode())
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -857,6 +857,37 @@ def test_bench_self_launches_and_proves_its_ranks():
     assert sp["n"] == 2 and sp["min"] <= sp["median"] <= sp["max"]
 
 
+def test_rccl_runs_on_this_box_with_one_rank():
+    """The pool hands out 1-GPU boxes and RCCL refuses two ranks on one device, so the N > 1 tests above go through gloo. This one
+    runs RCCL ITSELF with a world of one: init_process_group("nccl"), all_reduce / all_gather_object / all_gather_into_tensor on
+    device buffers, the asynchronous double-buffered exchange of bench.py (weak and strong mode), and the product's
+    dist.all_gather_tables on device memory — every call of the multi-GPU path, on a communicator of one."""
+    import subprocess
+    import sys
+    d = _bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--proteins-per-gpu", "2", "--no-extras"], {"TMPNN_BENCH_FORCE_GROUP": "1"})
+    c = d["collective"]
+    assert c["backend"].startswith("nccl") and c["world_size"] == 1 and c["ranks_seen"] == 1 and c["distinct_devices"] == 1
+    plain = _bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--proteins-per-gpu", "2", "--no-extras"])
+    assert "collective" not in plain and d["config"]["preds_per_step"] == plain["config"]["preds_per_step"]
+    s1 = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--scaling", "strong"], {"TMPNN_BENCH_FORCE_GROUP": "1"})
+    s0 = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--scaling", "strong"])
+    assert s1["checksum_listed"] == s0["checksum_listed"] and s1["excl_collective"]["value"] > 0     # gathered by RCCL == computed locally
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    code = ("import os, sys, socket, torch, torch.distributed as dist\n"
+            "sys.path.insert(0, %r)\n"
+            "from thermompnn_amd.dist import all_gather_tables\n"
+            "sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()\n"
+            "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')\n"
+            "torch.cuda.set_device(0)\n"
+            "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+            "x = torch.arange(5 * 22, dtype=torch.float32, device='cuda:0').reshape(5, 22)\n"
+            "got = all_gather_tables(x, [5])\n"
+            "assert dist.get_backend() == 'nccl' and len(got) == 1 and got[0].is_cuda and torch.equal(got[0], x)\n"
+            "dist.barrier(); dist.destroy_process_group(); print('rccl-ok')\n" % repo)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 def test_bench_strong_scaling_mode_is_rank_invariant():
     """--scaling strong = BASELINE configs[3] (300 proteins / 200 000 listed mutants, fixed total work). The listed values
     gathered from two ranks are the same numbers as from one (their float64 sum is bit-equal)."""

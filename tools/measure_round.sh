@@ -16,6 +16,8 @@ cp $(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kern
 python tools/rocprof_timed_stats.py $(find $O/prof_$TAG -name "*kernel_trace.csv" | head -1) 10 > $O/${TAG}_bench_kernel_stats_timed.csv
 python bench.py --scaling strong --steps 20 --warmup 5 > $O/${TAG}_bench_strong_1gpu.json 2> $O/${TAG}_bench_strong.err
 TMPNN_BENCH_ONE_DEVICE=1 TMPNN_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --proteins-per-gpu 8 --no-cpu-baseline > $O/${TAG}_bench_selflaunch_2ranks_one_device.json 2> $O/${TAG}_bench_selflaunch.err
+# RCCL itself, on this 1-GPU box: a process group of ONE rank (init_process_group("nccl"), device-buffer all_gather_into_tensor, the async overlap)
+TMPNN_BENCH_FORCE_GROUP=1 python bench.py --steps 20 --warmup 5 --no-extras > $O/${TAG}_bench_rccl_1rank.json 2> $O/${TAG}_bench_rccl_1rank.err
 bash tools/pmc_sq.sh > $O/${TAG}_pmc_sq.log 2>&1
 cp $O/pmc_sq_summary.txt $O/${TAG}_pmc_sq_summary.txt
 rm -rf $O/prof_$TAG/*/*.db 2>/dev/null
