@@ -1,0 +1,73 @@
+"""bench.py's roofline arithmetic and helpers, without a GPU: the numbers the JSON line derives from kernel durations."""
+import csv
+import io
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+sys.path.insert(0, REPO)
+
+
+def test_both_roofs_of_the_bench_batch():
+    """64 x L=256, K=48: the edge update moves 2 E_b + node operands = 825 229 312 algorithmic bytes and 77.3 GFLOP per launch; against
+    8 TB/s and 2.5 PF / 3 MFMAs that is 103.15 us (HBM) vs 92.77 us (MFMA): HBM binds, and `frac` is taken against it."""
+    import bench
+    T, edges = 16384, 16384 * 48
+    assert bench.kernel_bytes("enc_edge", T, edges) == 2 * 512.0 * edges + 2 * 512.0 * T + 192.0 * T == 825229312.0
+    assert bench.kernel_flops("enc_edge", T, edges) == 2.0 * edges * 3 * 128 * 128
+    r = bench.kernel_roofs("enc_edge", T, edges, 0.2933, "f16x2")
+    assert r["bound"] == "hbm" and abs(r["t_hbm_us"] - 103.1537) < 1e-3 and abs(r["t_mfma_us"] - 92.7713) < 1e-3
+    assert abs(r["frac"] - 103.1537 / 293.3) < 1e-4 and abs(r["hbm"]["achieved_GBps"] - 825229312.0 / 0.2933e-3 / 1e9) < 1e-6
+    assert r["mfma"]["terms"] == 3 and abs(r["mfma"]["peak_TFLOPs"] - 2500.0 / 3) < 1e-9
+    # the message kernels read h_E once: the matrix cores bind them (61.85 us vs 53.9 us of HBM)
+    m = bench.kernel_roofs("enc_msg", T, edges, 0.211, "f16x2")
+    assert m["bound"] == "mfma" and abs(m["t_mfma_us"] - 2.0 * edges * 2 * 128 * 128 / (2500e12 / 3) * 1e6) < 1e-6
+    # other precisions: bf16x3 = 6 MFMAs per multiply-accumulate on the per-edge kernels, fp32 MFMA everywhere else / in fp32 mode
+    assert bench.kernel_roofs("enc_edge", T, edges, 0.55, "bf16x3")["mfma"]["terms"] == 6
+    assert bench.kernel_roofs("node_update", T, edges, 0.04, "bf16x3")["mfma"]["terms"] == 0
+    f = bench.kernel_roofs("enc_edge", T, edges, 0.77, "fp32")
+    assert f["mfma"]["terms"] == 0 and f["mfma"]["peak_TFLOPs"] == bench.FP32_MFMA_PEAK_TFLOPS and f["bound"] == "mfma"
+    # a kernel without matrix work is judged on bytes alone
+    k = bench.kernel_roofs("knn", T, edges, 0.066, "f16x2")
+    assert k["bound"] == "hbm" and k["t_mfma_us"] == 0.0
+
+
+def test_usable_cpus_and_host_info():
+    import bench
+    n, quota = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1) and (quota is None or quota > 0)
+    info = bench.host_cpu_info()
+    assert info["affinity_cpus"] == n and info["host_cpus"] == os.cpu_count()
+
+
+def test_pmc_traffic_is_refused_for_other_batches_or_sources():
+    import bench
+    assert bench.pmc_traffic("enc_edge", 12345) is None                  # the PMC passes were taken at T = 16384 only
+    got = bench.pmc_traffic("enc_edge", 16384)
+    assert got is None or 0.99 < got / 825229312.0 < 1.05                # null (sources changed since the pass) or ~ the algorithmic bytes
+
+
+def test_rocprof_timed_stats_keeps_the_timed_launches_only(tmp_path):
+    """tools/rocprof_timed_stats.py: of a kernel trace with slow warm-up launches, only the last steps x launches-per-step count."""
+    rows = [("Kernel_Name", "Start_Timestamp", "End_Timestamp")]
+    t = 0
+    for step in range(7):                                                # 5 slow warm-up steps, then 2 timed ones
+        for name, per, dur in (("void enc_edge8_rp_kernel<SplitH2, false, true>(EdgeArgsB)", 3, 400 if step < 5 else 300),
+                               ("void knn_kernel<4>(float const*)", 1, 90 if step < 5 else 60), ("unrelated_kernel()", 1, 5)):
+            for _ in range(per):
+                rows.append((name, t, t + dur))
+                t += dur + 10
+    p = tmp_path / "trace.csv"
+    with open(p, "w", newline="") as fh:
+        csv.writer(fh).writerows(rows)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "rocprof_timed_stats.py"), str(p), "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = {row["Kernel_Name"]: row for row in csv.DictReader(io.StringIO(r.stdout))}
+    edge = out["void enc_edge8_rp_kernel<SplitH2, false, true>"]
+    assert int(edge["TimedLaunches"]) == 6 and float(edge["AvgNs"]) == 300.0 and int(edge["AllLaunches"]) == 21
+    assert abs(float(edge["AvgNsAllLaunches"]) - (15 * 400 + 6 * 300) / 21) < 0.1
+    assert float(out["void knn_kernel<4>"]["AvgNs"]) == 60.0 and "unrelated_kernel" not in out
