@@ -203,14 +203,136 @@ __device__ __forceinline__ void knn_row_reg(const float *__restrict__ X, const f
     }
 }
 
+// Threshold form of the register rows (round 3; default for NS = 4 / 8): instead of Keff dependent extract-min rounds (~30
+// instructions each) the wavefront
+//   1. finds a distance t with Keff <= #{candidates <= t} <= 64 — counting is 1 v_cmp + 1 s_bcnt1 per candidate register, every
+//      value wave-uniform; the search is a regula falsi on r^3 (neighbour counts grow like a volume) that falls back to bisecting
+//      the bit patterns every other step: 2-4 probes for a protein-like row;
+//   2. compacts those <= 64 candidates to one per lane (v_mbcnt of the ballots gives each its slot; 512 B of LDS per wavefront);
+//   3. sorts the 64 (distance bits, index) pairs with a bitonic network over the lanes (21 compare-exchange stages; partners
+//      fetched through the LDS crossbar, the min / max choice of a stage is a compile-time lane mask XOR-ed into the compare mask
+//      on the scalar unit), and lane t keeps the t-th neighbour.
+// Keys are (distance bits, index) exactly as in knn_row / knn_row_reg, so the neighbour list is the same list in the same order,
+// ties included. Rows where no such t exists (an exact tie straddling the 48th..64th place: masked-out rows, fewer than Keff
+// unmasked candidates) take the extract-min form.
+template <int J>
+__device__ __forceinline__ unsigned knn_xor_lane(unsigned x, int lane) {
+    return (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ J) << 2, (int)x);
+}
+template <int K2, int J>
+__device__ __forceinline__ void knn_bitonic_stage(unsigned &d, unsigned &j, int lane) {
+    // lanes that keep the LARGER of the pair: (lane & K2 != 0) xor (lane & J != 0)   (K2 = 64: ascending everywhere)
+    constexpr unsigned long long bitK = K2 >= 64 ? 0ull : ~0ull / ((1ull << K2) + 1ull) << K2;            // lanes with bit log2(K2) set
+    constexpr unsigned long long bitJ = ~0ull / ((1ull << J) + 1ull) << J;                                  // lanes with bit log2(J) set
+    constexpr unsigned long long keep_max = bitK ^ bitJ;
+    const unsigned pd = knn_xor_lane<J>(d, lane), pj = knn_xor_lane<J>(j, lane);
+    const unsigned long long less = __ballot(pd < d) | (__ballot(pd == d) & __ballot(pj < j));              // partner's key is smaller
+    const unsigned long long take = less ^ keep_max;          // keep-min lanes take a smaller partner, keep-max lanes a larger one (keys are distinct)
+    unsigned nd, nj;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nd) : "v"(d), "v"(pd), "s"(take));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nj) : "v"(j), "v"(pj), "s"(take));
+    d = nd;
+    j = nj;
+}
+template <int NS>
+__device__ __forceinline__ bool knn_row_sel(unsigned (*sel)[2], const float *__restrict__ X, const float *__restrict__ mask, int i, int s, int L,
+                                            int Keff, int lane, int32_t *__restrict__ E_idx, float *__restrict__ D_nb) {
+    const float xi = X[(size_t)i * 12 + 3], yi = X[(size_t)i * 12 + 4], zi = X[(size_t)i * 12 + 5];
+    const float mi = mask[i];
+    float D[NS], m2[NS];
+    float dmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {                              // (identical arithmetic to knn_row_reg / knn_row)
+        const int j = lane + 64 * k, jc = j < L ? j : 0;
+        const float *c = X + (size_t)(s + jc) * 12 + 3;
+        const float dx = c[0] - xi, dy = c[1] - yi, dz = c[2] - zi;
+        const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        m2[k] = mi * mask[s + jc];
+        D[k] = __fmul_rn(m2[k], sqrtf(__fadd_rn(s2, 1e-6f)));
+        if (j < L) dmax = fmaxf(dmax, D[k]);
+    }
+    dmax = wave_max_f32(dmax);
+    unsigned v[NS];
+    unsigned vmax = 0u;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const float Da = __fadd_rn(D[k], __fmul_rn(1.0f - m2[k], dmax));
+        const bool ok = lane + 64 * k < L;
+        v[k] = ok ? __float_as_uint(Da) : 0xffffffffu;           // distances are >= +0: their bits order like the values
+        if (ok) vmax = v[k] > vmax ? v[k] : vmax;
+    }
+    auto count = [&](unsigned tb) {                              // #{candidates <= tb}: wave-uniform
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) c += (int)__popcll(__ballot(v[k] <= tb));
+        return c;
+    };
+    unsigned tb;
+    if (L <= 64) {
+        tb = 0xfffffffeu;                                        // every real candidate (the empty slots hold 0xffffffff)
+    } else {
+        vmax = __float_as_uint(wave_max_f32(__uint_as_float(vmax)));           // (bit patterns of non-negative floats order like the floats)
+        unsigned lo = 0u, hi = vmax;                             // count(lo - 1) < Keff (nothing below +0), count(hi) = L > 64
+        int clo = 0, chi = L;
+        const float aim = 0.5f * (float)(Keff + 64);
+        bool found = false;
+        for (int it = 0; it < 14; ++it) {
+            if (hi - lo <= 1u) break;                            // no pattern strictly between: an exact tie straddles the window
+            unsigned t;
+            if (it & 1) {
+                t = lo + ((hi - lo) >> 1);                       // bisection step (bit patterns)
+            } else {                                             // regula falsi on r^3
+                const float rl = __uint_as_float(lo), rh = __uint_as_float(hi);
+                const float x = (aim - (float)clo) / (float)(chi - clo);
+                const float c3 = rl * rl * rl + x * (rh * rh * rh - rl * rl * rl);
+                const float r = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(fmaxf(c3, 1e-30f)) * (1.0f / 3.0f));
+                t = __float_as_uint(r);
+                if (!(t > lo && t < hi)) t = lo + ((hi - lo) >> 1);
+            }
+            const int c = count(t);
+            if (c >= Keff && c <= 64) { tb = t; found = true; break; }
+            if (c < Keff) { lo = t; clo = c; } else { hi = t; chi = c; }
+        }
+        if (!found) return false;
+    }
+    // compaction: candidate (lane, k) with v <= tb goes to slot (#selected before it in k-major, lane-minor order)
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const bool in = v[k] <= tb;
+        const unsigned long long mk = __ballot(in);
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, (unsigned)base));
+        if (in) { sel[pos][0] = v[k]; sel[pos][1] = (unsigned)(lane + 64 * k); }
+        base += (int)__popcll(mk);
+    }
+    wave_lds_fence();
+    unsigned d = lane < base ? sel[lane][0] : 0xffffffffu, j = lane < base ? sel[lane][1] : 0xffffffffu;
+    wave_lds_fence();
+    knn_bitonic_stage<2, 1>(d, j, lane);
+    knn_bitonic_stage<4, 2>(d, j, lane);  knn_bitonic_stage<4, 1>(d, j, lane);
+    knn_bitonic_stage<8, 4>(d, j, lane);  knn_bitonic_stage<8, 2>(d, j, lane);  knn_bitonic_stage<8, 1>(d, j, lane);
+    knn_bitonic_stage<16, 8>(d, j, lane); knn_bitonic_stage<16, 4>(d, j, lane); knn_bitonic_stage<16, 2>(d, j, lane);
+    knn_bitonic_stage<16, 1>(d, j, lane);
+    knn_bitonic_stage<32, 16>(d, j, lane); knn_bitonic_stage<32, 8>(d, j, lane); knn_bitonic_stage<32, 4>(d, j, lane);
+    knn_bitonic_stage<32, 2>(d, j, lane);  knn_bitonic_stage<32, 1>(d, j, lane);
+    knn_bitonic_stage<64, 32>(d, j, lane); knn_bitonic_stage<64, 16>(d, j, lane); knn_bitonic_stage<64, 8>(d, j, lane);
+    knn_bitonic_stage<64, 4>(d, j, lane);  knn_bitonic_stage<64, 2>(d, j, lane);  knn_bitonic_stage<64, 1>(d, j, lane);
+    if (lane < TM_KS) {                                          // slots >= Keff keep (-1, 0)
+        E_idx[(size_t)i * TM_KS + lane] = lane < Keff ? s + (int)j : -1;
+        D_nb[(size_t)i * TM_KS + lane] = lane < Keff ? __uint_as_float(d) : 0.f;
+    }
+    return true;
+}
+
 // NS = 0: rows of any length through LDS (knn_row); NS = 4 / 8: every row of the batch has at most 256 / 512 residues
 // (max_len says so) and runs in registers (knn_row_reg) — no dynamic LDS at all.
 template <int NS>
 __global__ __launch_bounds__(TM_THREADS, NS == 8 ? 4 : 8) void knn_kernel(const float *__restrict__ X, const float *__restrict__ mask,
                                                             const int32_t *__restrict__ offsets, int N, int T, int max_len,
                                                             int K, int32_t *__restrict__ E_idx, float *__restrict__ D_nb,
-                                                            int32_t *__restrict__ status, KnnInit init) {
+                                                            int32_t *__restrict__ status, KnnInit init, int sel_rows) {
     extern __shared__ __attribute__((aligned(16))) float knn_lds[];
+    __shared__ unsigned s_sel[NS > 0 ? 4 : 1][64][2];        // compaction slots of knn_row_sel, one set per wavefront
     const int lane = tm_tid() & 63, wv = tm_wave(tm_tid());
     float *d = knn_lds + (size_t)wv * (max_len + (max_len >> 6) + 1);
 
@@ -232,8 +354,10 @@ __global__ __launch_bounds__(TM_THREADS, NS == 8 ? 4 : 8) void knn_kernel(const 
             continue;
         }
         const int Keff = K < L ? K : L;
-        if constexpr (NS > 0) knn_row_reg<NS>(X, mask, i, s, L, Keff, lane, E_idx, D_nb);
-        else if (L > 512) knn_row<true>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
+        if constexpr (NS > 0) {
+            if (!sel_rows || !knn_row_sel<NS>(s_sel[wv], X, mask, i, s, L, Keff, lane, E_idx, D_nb))
+                knn_row_reg<NS>(X, mask, i, s, L, Keff, lane, E_idx, D_nb);
+        } else if (L > 512) knn_row<true>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
         else knn_row<false>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
     }
 }
@@ -719,14 +843,15 @@ int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N,
     const int64_t cap = (int64_t)tm_num_cus() * 8;
     const int grid = (int)(blocks < cap ? blocks : cap);
     static const bool reg_rows = [] { const char *e = getenv("TMPNN_KNN_REG"); return !(e && e[0] == '0'); }();
+    static const int sel_rows = [] { const char *e = getenv("TMPNN_KNN_SEL"); return (e && e[0] == '0') ? 0 : 1; }();   // 0: extract-min rounds only (A/B)
     tm_prof_begin("knn", st);
-    if (reg_rows && max_len <= 256) knn_kernel<4><<<grid, TM_THREADS, 0, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init);
-    else if (reg_rows && max_len <= 512) knn_kernel<8><<<grid, TM_THREADS, 0, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init);
+    if (reg_rows && max_len <= 256) knn_kernel<4><<<grid, TM_THREADS, 0, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init, sel_rows);
+    else if (reg_rows && max_len <= 512) knn_kernel<8><<<grid, TM_THREADS, 0, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init, sel_rows);
     else {
         // per call, not cached: the attribute is per device and one process may drive several GPUs
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        knn_kernel<0><<<grid, TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init);
+        knn_kernel<0><<<grid, TM_THREADS, lds, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init, 0);
     }
     tm_prof_end(st);
     return tm_check_launch("knn_topk");
