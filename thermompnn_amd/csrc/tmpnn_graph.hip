@@ -222,7 +222,7 @@ __device__ __forceinline__ unsigned knn_xor_lane(unsigned x, int lane) {
 template <int K2, int J>
 __device__ __forceinline__ void knn_bitonic_stage(unsigned &d, unsigned &j, int lane) {
     // lanes that keep the LARGER of the pair: (lane & K2 != 0) xor (lane & J != 0)   (K2 = 64: ascending everywhere)
-    constexpr unsigned long long bitK = K2 >= 64 ? 0ull : ~0ull / ((1ull << K2) + 1ull) << K2;            // lanes with bit log2(K2) set
+    constexpr unsigned long long bitK = K2 >= 64 ? 0ull : ~0ull / ((1ull << (K2 & 63)) + 1ull) << (K2 & 63);           // lanes with bit log2(K2) set
     constexpr unsigned long long bitJ = ~0ull / ((1ull << J) + 1ull) << J;                                  // lanes with bit log2(J) set
     constexpr unsigned long long keep_max = bitK ^ bitJ;
     const unsigned pd = knn_xor_lane<J>(d, lane), pj = knn_xor_lane<J>(j, lane);
@@ -542,6 +542,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 1)) void featurize_kernel(F
 #ifndef TM_FEAT_PF
 #define TM_FEAT_PF 1      // B-fragment prefetch distance of GEMM 1 (mma_tile_split): 1 = 0.500 ms with 38 spilled VGPRs (reloaded around the GEMM, not in it) against 0.524 at 0 (13 spilled), 0.527 at 2
 #endif
+#ifndef TM_FEAT_DMA
+#define TM_FEAT_DMA 1     // 1: the next tile's rows go global -> LDS by LDS-DMA, issued before the Gaussians (see the kernel); 0: through 18
+                          // VGPRs of every wavefront, issued after them (round 2)
+#endif
+// one LDS-DMA piece: lane l's 16 (4) bytes at `src` land at LDS byte address lds + 16 (4) * l (wave-uniform base in M0; retired
+// through vmcnt). Inline asm ON PURPOSE: with the builtin, hipcc orders every later ds_read of the wavefront behind the piece
+// (s_waitcnt vmcnt(0) in front of the first LDS read — here the Gaussians), which exposes exactly the latency the piece is
+// issued early to hide. The compiler does not count these in its vmcnt bookkeeping, so its own waits can only over-wait;
+// the consumer waits explicitly (`publish`).
+__device__ __forceinline__ unsigned tm_lds_addr(const void *p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ void tm_glds16(const void *src, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void tm_glds4(const void *src, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
+}
 // PROF: phase timing (s_memtime deltas of thread 0 of workgroup 0, summed over its tiles) into prof[0..7] — TMPNN_FEAT_PROF=1
 template <typename SP, bool PROF = false, bool IMG = false>
 __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, unsigned long long *prof = nullptr) {
@@ -562,8 +580,8 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
     __shared__ float s_atoms[TM_TILE][16];
     __shared__ float s_self[16];
     __shared__ float s_dist[TM_TILE][28];
-    __shared__ int s_idx[2][TM_TILE];
-    __shared__ int s_dpos[2][TM_TILE];
+    __shared__ int s_ix[2][2][TM_TILE];                      // [buffer][neighbour index | positional index][neighbour]: ONE array, one lane base
+    __shared__ __attribute__((aligned(16))) float s_const[3][TM_H];   // W_e bias, LayerNorm gain / bias: read where used, not held (12 VGPRs)
     char *tAp = rbf;
     const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31;
@@ -591,19 +609,71 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
         load_wfrag_split<SP, 13>(a.edge_w, 416, 16 * wv, 16, 400, wedge[0], lane);
         load_wfrag_split<SP, 4>(a.We_w, TM_H, 16 * wv, 0, TM_H, we[0], lane);
     }
-    const f4 be = ld4(a.We_b + ncol);
-    const f4 g4 = ld4(a.ln_w + ncol), b4 = ld4(a.ln_b + ncol);
+    if (tid < 3 * TM_H / 4) {
+        const int w = tid >> 5, c = 4 * (tid & 31);
+        st4(&s_const[w][c], ld4((w == 0 ? a.We_b : w == 1 ? a.ln_w : a.ln_b) + c));   // visible after the prologue's barriers
+    }
     f4 mu4;                                                   // this thread's 4 Gaussian centres: (tid & 3) is fixed
 #pragma unroll
     for (int r = 0; r < 4; ++r) mu4[r] = a.mu[(tid & 3) * 4 + r];
+    // consumed HERE so that the wait for this load sits in the prologue: left pending, the compiler's scoreboard puts a
+    // vmcnt(N) into the Gaussian loop of every tile, which (vmcnt retires in order) waits for the DMA pieces issued in front of it
+    asm volatile("" ::"v"(mu4.x), "v"(mu4.y), "v"(mu4.z), "v"(mu4.w));
 
-    // Per-tile inputs (neighbour list, 5 atoms of every neighbour, positional index, Ca-Ca distance) are fetched into
-    // registers by 49 threads one tile ahead — the dependent global loads (E_idx -> X[j]) fly under GEMM 1.
-    // (A two-deep variant — list of tile i+2, rows of tile i+1 — was measured: no gain; GEMM 1 was LDS-latency bound.)
+    // Per-tile inputs (neighbour list, 5 atoms of every neighbour, positional index, Ca-Ca distance), one tile ahead.
+    // TM_FEAT_DMA = 1 (round 3): the phase profile showed GEMM 1 at 1.85 x its matrix time only because wavefront 0 met the
+    // dependent global loads (E_idx -> X[j]) in front of it — vmcnt retires in order, so the accumulator rows issued behind
+    // them waited for both latencies (2 600 of the tile's 17 300 cycles), and the 18 registers holding the rows across the
+    // GEMM were spilled and reloaded in `publish` (900 cycles, serial). Now: the list entry of tile i+2 is an ordinary load
+    // (1 VGPR, consumed one tile later); the rows of tile i+1 go global -> LDS by LDS-DMA, issued by wavefront 0 (neighbours)
+    // and 1 (the residue itself) BEFORE the Gaussians, which outlast their latency; this tile's positional rows are loaded
+    // into the accumulators at the same point. `publish` reads the raw rows back, adds the virtual Cb and writes the tables
+    // `distances` uses. (All 64 lanes of both wavefronts issue: lanes >= 48 duplicate neighbour 47, so no EXEC-masked DMA.)
+    // TM_FEAT_DMA = 0: registers, issued after the Gaussians; a two-deep variant of that form was measured in round 2: no gain.
+#if TM_FEAT_DMA
+    __shared__ __attribute__((aligned(16))) float s_raw[2][3][64][4];   // [neighbours | self][16-byte piece of the 48-byte row][lane]
+    __shared__ int s_misc[6][64];                            // per neighbour: masked Ca-Ca distance, residue_idx[j], chain[j]; residue_idx[i], chain[i]; j
+#endif
+#if TM_FEAT_DMA
+    int g_jn = -1;                                            // the only per-tile value held in a register: list entry of tile i+2
+#else
     float g_at[15];
     float g_d0 = 0.f;
     int g_idx = -1, g_dpos = 0;
+#endif
+    // (lane offsets laundered through an empty asm: otherwise the compiler hoists base + lane as 64-bit pairs out of the tile
+    //  loop, spills them, and the reload's vmcnt(0) — in order behind the DMA pieces — waits for the pieces)
+#if TM_FEAT_DMA
+    auto fetch_list = [&](int ii) {
+        int lt = tid;
+        asm volatile("" : "+v"(lt));
+        if (tid < TM_TILE) g_jn = (a.E_idx + (size_t)ii * TM_KS)[lt];
+    };
+#endif
     auto fetch = [&](int ii) {
+#if TM_FEAT_DMA
+        if (wv == 0) {
+            int nb = tid < TM_TILE ? tid : TM_TILE - 1;
+            asm volatile("" : "+v"(nb));
+            const int jn = __builtin_amdgcn_ds_bpermute(4 * nb, g_jn);
+            const int jj = jn < 0 ? ii : jn;
+            const float *x = a.X + (size_t)jj * 12;
+            tm_glds16(x, tm_lds_addr(&s_raw[0][0][0][0]));
+            tm_glds16(x + 4, tm_lds_addr(&s_raw[0][1][0][0]));
+            tm_glds16(x + 8, tm_lds_addr(&s_raw[0][2][0][0]));
+            tm_glds4((a.D_nb + (size_t)ii * TM_KS) + nb, tm_lds_addr(s_misc[0]));   // masked Ca-Ca distance from _dist (:1142)
+            tm_glds4(a.ridx + jj, tm_lds_addr(s_misc[1]));
+            tm_glds4(a.cenc + jj, tm_lds_addr(s_misc[2]));
+            tm_glds4(a.ridx + ii, tm_lds_addr(s_misc[3]));        // (every lane the same word: no scalar load in `publish`)
+            tm_glds4(a.cenc + ii, tm_lds_addr(s_misc[4]));
+            tm_glds4((a.E_idx + (size_t)ii * TM_KS) + nb, tm_lds_addr(s_misc[5]));   // the list entry again: not held across the GEMM
+        } else if (wv == 1) {
+            const float *x = a.X + (size_t)ii * 12;
+            tm_glds16(x, tm_lds_addr(&s_raw[1][0][0][0]));
+            tm_glds16(x + 4, tm_lds_addr(&s_raw[1][1][0][0]));
+            tm_glds16(x + 8, tm_lds_addr(&s_raw[1][2][0][0]));
+        }
+#else
         if (tid < TM_TILE) {
             const int j = a.E_idx[(size_t)ii * TM_KS + tid];
             g_idx = j;
@@ -616,11 +686,40 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
         } else if (tid == 64) {
             atoms5(a.X + (size_t)ii * 12, g_at);
         }
+#endif
     };
     auto publish = [&](int buf) {
+#if TM_FEAT_DMA
+        // (everything local: a value assigned under a wavefront test and declared outside the tile loop is carried through
+        //  it as a phi in every wavefront — 17 VGPRs of pressure in the round-2 form)
+        if (wv < 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wavefront's DMA pieces have landed
+            float x[12], at[15];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f4 v = ld4(&s_raw[wv][c][lane][0]);
+                x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+            }
+            atoms5(x, at);
+            if (wv == 1) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) s_self[k] = at[k];
+                }
+            } else if (lane < TM_TILE) {
+                const int off = s_misc[3][lane] - s_misc[1][lane];   // PositionalEncodings index (:903-905, :1170-1175)
+                const int same = s_misc[4][lane] == s_misc[2][lane];
+                s_ix[buf][0][lane] = s_misc[5][lane];
+                s_ix[buf][1][lane] = same ? min(max(off + 32, 0), 64) : 65;
+#pragma unroll
+                for (int k = 0; k < 15; ++k) s_atoms[lane][k] = at[k];
+                s_atoms[lane][15] = __builtin_bit_cast(float, s_misc[0][lane]);
+            }
+        }
+#else
         if (tid < TM_TILE) {
-            s_idx[buf][tid] = g_idx;
-            s_dpos[buf][tid] = g_dpos;
+            s_ix[buf][0][tid] = g_idx;
+            s_ix[buf][1][tid] = g_dpos;
 #pragma unroll
             for (int k = 0; k < 15; ++k) s_atoms[tid][k] = g_at[k];
             s_atoms[tid][15] = g_d0;
@@ -628,6 +727,7 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
 #pragma unroll
             for (int k = 0; k < 15; ++k) s_self[k] = g_at[k];
         }
+#endif
     };
     auto distances = [&]() {                                    // 25 atom-pair distances of the 48 neighbours
         for (int e = tid; e < TM_TILE * 25; e += 512) {
@@ -652,7 +752,13 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin, cur = 0;
     if (i < tr.end) {
+#if TM_FEAT_DMA
+        fetch_list(i);
         fetch(i);
+        if (i + tr.step < tr.end) fetch_list(i + tr.step);
+#else
+        fetch(i);
+#endif
         publish(0);
         __syncthreads();
         distances();
@@ -666,6 +772,15 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
             const int p = tid / (TM_TILE * 2), rem = tid - p * (TM_TILE * 2);
             *reinterpret_cast<u4 *>(rbf + plane_off8<TM_TILE, RBFP_ROWB>(p, rem >> 1, 50 + (rem & 1))) = u4{0u, 0u, 0u, 0u};
         }
+        f4 acc[3][1];
+#if TM_FEAT_DMA
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_ix[cur][1][16 * rb + m] * TM_H + ncol);
+        if (has_next) {
+            fetch(inext);
+            if (inext + tr.step < tr.end) fetch_list(inext + tr.step);
+        }
+#endif
 #if TM_ABL_NOGAUSS
         if (false)
 #endif
@@ -686,10 +801,11 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
         __syncthreads();                                       // RBF planes complete; s_dist / s_atoms consumed
         mark(1);
 
-        if (has_next) fetch(inext);
-        f4 acc[3][1];
+        if (!TM_FEAT_DMA) {
+            if (has_next) fetch(inext);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_dpos[cur][16 * rb + m] * TM_H + ncol);
+            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_ix[cur][1][16 * rb + m] * TM_H + ncol);
+        }
         mma_tile_split<SP, 13, 1, 3, TM_TILE, RBFP_ROWB, 13, 0, true, TM_FEAT_PF>(rbf, wedge, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) row_stats_partial1b(acc[rb][0], &s_stat[16 * rb + m][2 * wv], q);
@@ -703,9 +819,9 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
             const int row = 16 * rb + m;
             float mean, rstd;
             row_stats_finish8b(&s_stat[row][0], mean, rstd);
-            const f4 y = (acc[rb][0] - mean) * rstd * g4 + b4;
+            const f4 y = (acc[rb][0] - mean) * rstd * ld4(&s_const[1][ncol]) + ld4(&s_const[2][ncol]);
             store_split<SP>(tAp, row, c4, y);
-            if (a.E_opt) st4(a.E_opt + ((size_t)i * TM_KS + row) * TM_H + ncol, s_idx[cur][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
+            if (a.E_opt) st4(a.E_opt + ((size_t)i * TM_KS + row) * TM_H + ncol, s_ix[cur][0][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
         }
         mark(5);
         if (has_next) distances();
@@ -713,7 +829,7 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
         __syncthreads();
         mark(7);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = be;
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(&s_const[0][ncol]);
         mma_tile_split<SP, 4, 1>(tAp, we, acc, lane);           // W_e (:1229)
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) st4(tB + chunk_off(16 * rb + m, c4), acc[rb][0]);
@@ -723,12 +839,12 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int row = 6 * wv + 2 * it + (lane >> 5);
-            const f4 y = s_idx[cur][row] >= 0 ? ld4(tB + chunk_off(row, c32)) : f4{0.f, 0.f, 0.f, 0.f};
+            const f4 y = s_ix[cur][0][row] >= 0 ? ld4(tB + chunk_off(row, c32)) : f4{0.f, 0.f, 0.f, 0.f};
             st4(a.hE + ((size_t)i * TM_KS + row) * TM_H + 4 * c32, y);
         }
         mark(10);
         cur ^= 1;
-        // no barrier: tB is rewritten only after three more barriers, s_idx[cur^1] after one
+        // no barrier: tB is rewritten only after three more barriers, s_ix[cur^1] after one
     }
 }
 
