@@ -302,13 +302,14 @@ extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const 
     int rc = launch_prep_tables(w, (hipStream_t)stream);
     if (mode == TM_MM_F16X2) {   // fragment images of every 128 x 128 block the f16x2 kernels multiply by (see WImg); no other mode reads them
         char *img = (char *)p;
-        auto add = [&](const float *base, int ld, int n_rows = 128, int k_valid = 128) {
+        auto add = [&](const float *base, int ld, int n_rows = 128, int k_valid = 128, int k_wrap = 0) {
             if (rc != TMPNN_OK || w->n_wimg >= TM_N_WIMG) return;
             w->wimg[w->n_wimg++] = WImg{base, img};
-            rc = launch_prep_wimg(base, ld, img, (hipStream_t)stream, n_rows, k_valid);
+            rc = launch_prep_wimg(base, ld, img, (hipStream_t)stream, n_rows, k_valid, k_wrap);
             img += TM_WIMG_BYTES;
         };
-        for (int b = 0; b < 4; ++b) add(w->edge_w + 16 + 128 * b, 416, 128, b < 3 ? 128 : 16);   // RBF columns 16..415 (K padded to 416 + 96)
+        // RBF columns 16..415 (K padded to 416 + 96), then — K positions 400..415 — the 16 positional columns 0..15 of the same rows
+        for (int b = 0; b < 4; ++b) add(w->edge_w + 16 + 128 * b, 416, 128, b < 3 ? 128 : 16, b < 3 ? 0 : 16);
         add(w->We_w, 128);
         if (n_tensors == TMPNN_N_TENSORS) {          // ddG head: centre tap (derived just above, on the same stream) + both_out.1
             for (int u = 0; u < 9; ++u) add(w->conv_center + (size_t)128 * (u / 3) * 384 + 128 * (u % 3), 384);

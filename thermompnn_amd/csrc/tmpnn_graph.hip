@@ -375,6 +375,7 @@ __constant__ int c_pair_b[25] = {1, 0, 2, 3, 4, 0, 2, 3, 4, 2, 3, 4, 2, 3, 2, 1,
 struct FeatArgs {
     const float *edge_w;     // [128,416]
     const float *pos_table;  // [66,128]
+    const float *pos_w, *pos_b;   // features.embeddings.linear [16,66], [16]
     const float *ln_w, *ln_b, *We_w, *We_b;
     const float *X;          // [T,4,3]
     const int32_t *ridx, *cenc, *E_idx;
@@ -542,6 +543,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 1)) void featurize_kernel(F
 #ifndef TM_FEAT_PF
 #define TM_FEAT_PF 1      // B-fragment prefetch distance of GEMM 1 (mma_tile_split): 1 = 0.500 ms with 38 spilled VGPRs (reloaded around the GEMM, not in it) against 0.524 at 0 (13 spilled), 0.527 at 2
 #endif
+#ifndef TM_FEAT_DIST2
+#define TM_FEAT_DIST2 1
+#endif
 #ifndef TM_FEAT_DMA
 #define TM_FEAT_DMA 1     // 1: the next tile's rows go global -> LDS by LDS-DMA, issued before the Gaussians (see the kernel); 0: through 18
                           // VGPRs of every wavefront, issued after them (round 2)
@@ -606,13 +610,23 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
             we[0][c].p[1] = *reinterpret_cast<const u4 *>(pw + 2048 * c + 1024);
         }
     } else {
-        load_wfrag_split<SP, 13>(a.edge_w, 416, 16 * wv, 16, 400, wedge[0], lane);
+        load_wfrag_split<SP, 13>(a.edge_w, 416, 16 * wv, 16, 400, wedge[0], lane, 16);
         load_wfrag_split<SP, 4>(a.We_w, TM_H, 16 * wv, 0, TM_H, we[0], lane);
     }
     if (tid < 3 * TM_H / 4) {
         const int w = tid >> 5, c = 4 * (tid & 31);
         st4(&s_const[w][c], ld4((w == 0 ? a.We_b : w == 1 ? a.ln_w : a.ln_b) + c));   // visible after the prologue's barriers
     }
+#if TM_FEAT_DMA
+    // PositionalEncodings (:896-908) = one_hot(d) . W_pos^T + b_pos: 16 values per edge, a 66-row table in LDS. They ride GEMM 1
+    // in its K padding (columns 400..415 against edge_embedding.weight[:, 0:16]) instead of arriving as accumulator rows from
+    // a [66,128] global table: no global load between the tile loop's barriers at all
+    __shared__ __attribute__((aligned(16))) float s_pos[66][16];
+    for (int e = tid; e < 66 * 16; e += 512) {
+        const int d = e >> 4, pp = e & 15;
+        s_pos[d][pp] = a.pos_w[pp * 66 + d] + a.pos_b[pp];
+    }
+#endif
     f4 mu4;                                                   // this thread's 4 Gaussian centres: (tid & 3) is fixed
 #pragma unroll
     for (int r = 0; r < 4; ++r) mu4[r] = a.mu[(tid & 3) * 4 + r];
@@ -631,11 +645,11 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
     // `distances` uses. (All 64 lanes of both wavefronts issue: lanes >= 48 duplicate neighbour 47, so no EXEC-masked DMA.)
     // TM_FEAT_DMA = 0: registers, issued after the Gaussians; a two-deep variant of that form was measured in round 2: no gain.
 #if TM_FEAT_DMA
-    __shared__ __attribute__((aligned(16))) float s_raw[2][3][64][4];   // [neighbours | self][16-byte piece of the 48-byte row][lane]
-    __shared__ int s_misc[6][64];                            // per neighbour: masked Ca-Ca distance, residue_idx[j], chain[j]; residue_idx[i], chain[i]; j
-#endif
-#if TM_FEAT_DMA
-    int g_jn = -1;                                            // the only per-tile value held in a register: list entry of tile i+2
+    __shared__ __attribute__((aligned(16))) float s_raw[3][64][4];   // neighbours' rows: [16-byte piece of the 48-byte row][lane]
+    __shared__ __attribute__((aligned(16))) float s_sraw[64];        // the residue's own row, one word per lane (12 used)
+    __shared__ int s_misc[3][64];                            // per neighbour: masked Ca-Ca distance, residue_idx[j], chain[j]; lane 48 of the last two: [i]
+    __shared__ int s_list[2][64];                            // neighbour lists, two tiles ahead: [tile parity][neighbour]
+    const int wu = __builtin_amdgcn_readfirstlane(wv);       // scalar branches around the pieces
 #else
     float g_at[15];
     float g_d0 = 0.f;
@@ -644,36 +658,37 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
     // (lane offsets laundered through an empty asm: otherwise the compiler hoists base + lane as 64-bit pairs out of the tile
     //  loop, spills them, and the reload's vmcnt(0) — in order behind the DMA pieces — waits for the pieces)
 #if TM_FEAT_DMA
-    auto fetch_list = [&](int ii) {
-        int lt = tid;
-        asm volatile("" : "+v"(lt));
-        if (tid < TM_TILE) g_jn = (a.E_idx + (size_t)ii * TM_KS)[lt];
-    };
-#endif
-    auto fetch = [&](int ii) {
-#if TM_FEAT_DMA
-        if (wv == 0) {
-            int nb = tid < TM_TILE ? tid : TM_TILE - 1;
-            asm volatile("" : "+v"(nb));
-            const int jn = __builtin_amdgcn_ds_bpermute(4 * nb, g_jn);
-            const int jj = jn < 0 ? ii : jn;
-            const float *x = a.X + (size_t)jj * 12;
-            tm_glds16(x, tm_lds_addr(&s_raw[0][0][0][0]));
-            tm_glds16(x + 4, tm_lds_addr(&s_raw[0][1][0][0]));
-            tm_glds16(x + 8, tm_lds_addr(&s_raw[0][2][0][0]));
-            tm_glds4((a.D_nb + (size_t)ii * TM_KS) + nb, tm_lds_addr(s_misc[0]));   // masked Ca-Ca distance from _dist (:1142)
+    // the 8 pieces of one tile, ONE per wavefront (a piece costs its wavefront several hundred cycles of issue): rows of tile ii
+    // through its list in s_list[lb] (landed a tile ago), and the list of tile i2 (two ahead; < 0: none) into s_list[lb ^ 1].
+    // Lanes 48..63 of the per-neighbour pieces address the residue itself: lane 48 of residue_idx / chain is what `publish`
+    // compares against, no separate piece and no scalar load for them.
+    auto fetch = [&](int ii, int lb, int i2) {
+        int nb = lane < TM_TILE ? lane : TM_TILE - 1;
+        asm volatile("" : "+v"(nb));
+        const int jn = lane < TM_TILE ? s_list[lb][nb] : -1;
+        const int jj = jn < 0 ? ii : jn;
+        const float *x = a.X + (size_t)jj * 12;
+        if (wu == 0) {
+            tm_glds16(x, tm_lds_addr(&s_raw[0][0][0]));
+        } else if (wu == 1) {
+            tm_glds16(x + 4, tm_lds_addr(&s_raw[1][0][0]));
+        } else if (wu == 2) {
+            tm_glds16(x + 8, tm_lds_addr(&s_raw[2][0][0]));
+        } else if (wu == 3) {
+            tm_glds4(a.X + (size_t)ii * 12 + (lane < 12 ? lane : 11), tm_lds_addr(s_sraw));
+        } else if (wu == 4) {
             tm_glds4(a.ridx + jj, tm_lds_addr(s_misc[1]));
+        } else if (wu == 5) {
             tm_glds4(a.cenc + jj, tm_lds_addr(s_misc[2]));
-            tm_glds4(a.ridx + ii, tm_lds_addr(s_misc[3]));        // (every lane the same word: no scalar load in `publish`)
-            tm_glds4(a.cenc + ii, tm_lds_addr(s_misc[4]));
-            tm_glds4((a.E_idx + (size_t)ii * TM_KS) + nb, tm_lds_addr(s_misc[5]));   // the list entry again: not held across the GEMM
-        } else if (wv == 1) {
-            const float *x = a.X + (size_t)ii * 12;
-            tm_glds16(x, tm_lds_addr(&s_raw[1][0][0][0]));
-            tm_glds16(x + 4, tm_lds_addr(&s_raw[1][1][0][0]));
-            tm_glds16(x + 8, tm_lds_addr(&s_raw[1][2][0][0]));
+        } else if (wu == 6) {
+            tm_glds4((a.D_nb + (size_t)ii * TM_KS) + nb, tm_lds_addr(s_misc[0]));   // masked Ca-Ca distance from _dist (:1142)
+        } else if (i2 >= 0) {
+            tm_glds4((a.E_idx + (size_t)i2 * TM_KS) + nb, tm_lds_addr(s_list[lb ^ 1]));
         }
+    };
+    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };   // in front of the barrier that publishes the pieces
 #else
+    auto fetch = [&](int ii) {
         if (tid < TM_TILE) {
             const int j = a.E_idx[(size_t)ii * TM_KS + tid];
             g_idx = j;
@@ -686,30 +701,29 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
         } else if (tid == 64) {
             atoms5(a.X + (size_t)ii * 12, g_at);
         }
-#endif
     };
-    auto publish = [&](int buf) {
+#endif
+    auto publish = [&](int buf, int lb) {
 #if TM_FEAT_DMA
         // (everything local: a value assigned under a wavefront test and declared outside the tile loop is carried through
         //  it as a phi in every wavefront — 17 VGPRs of pressure in the round-2 form)
-        if (wv < 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wavefront's DMA pieces have landed
+        if (wu < 2) {                                           // (the pieces landed before the last barrier)
             float x[12], at[15];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const f4 v = ld4(&s_raw[wv][c][lane][0]);
+                const f4 v = wu == 0 ? ld4(&s_raw[c][lane][0]) : ld4(&s_sraw[4 * c]);
                 x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
             }
             atoms5(x, at);
-            if (wv == 1) {
+            if (wu == 1) {
                 if (lane == 0) {
 #pragma unroll
                     for (int k = 0; k < 15; ++k) s_self[k] = at[k];
                 }
             } else if (lane < TM_TILE) {
-                const int off = s_misc[3][lane] - s_misc[1][lane];   // PositionalEncodings index (:903-905, :1170-1175)
-                const int same = s_misc[4][lane] == s_misc[2][lane];
-                s_ix[buf][0][lane] = s_misc[5][lane];
+                const int off = s_misc[1][TM_TILE] - s_misc[1][lane];   // PositionalEncodings index (:903-905, :1170-1175)
+                const int same = s_misc[2][TM_TILE] == s_misc[2][lane];
+                s_ix[buf][0][lane] = s_list[lb][lane];
                 s_ix[buf][1][lane] = same ? min(max(off + 32, 0), 64) : 65;
 #pragma unroll
                 for (int k = 0; k < 15; ++k) s_atoms[lane][k] = at[k];
@@ -729,37 +743,56 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
         }
 #endif
     };
-    auto distances = [&]() {                                    // 25 atom-pair distances of the 48 neighbours
-        for (int e = tid; e < TM_TILE * 25; e += 512) {
-            const int mm = e / 25, p = e - mm * 25;
-            float D;
-            if (p == 0) {
-                D = s_atoms[mm][15];
-            } else {
-                // atom indices of pair p (c_pair_a / c_pair_b, 3 bits each) from immediates: no per-lane constant-memory load
-                const int sh = 3 * (p & 15);
-                const int ia = (int)(((p < 16 ? 0xe400124c681ull : 0x26a351aull) >> sh) & 7ull);
-                const int ib = (int)(((p < 16 ? 0x29a8d4684681ull : 0x3900049ull) >> sh) & 7ull);
-                const float *A = s_self + 3 * ia;
-                const float *B = s_atoms[mm] + 3 * ib;
-                const float dx = A[0] - B[0], dy = A[1] - B[1], dz = A[2] - B[2];
-                D = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);  // _get_rbf (:1122); v_sqrt_f32, 1 ulp
-            }
-            s_dist[mm][p] = D;
+    // 25 atom-pair distances of the 48 neighbours: 1 200 values over 512 threads
+    auto dist_one = [&](int e) {
+        const int mm = e / 25, p = e - mm * 25;
+        // atom indices of pair p (c_pair_a / c_pair_b, 3 bits each) from immediates: no per-lane constant-memory load
+        const int sh = 3 * (p & 15);
+        const int ia = (int)(((p < 16 ? 0xe400124c681ull : 0x26a351aull) >> sh) & 7ull);
+        const int ib = (int)(((p < 16 ? 0x29a8d4684681ull : 0x3900049ull) >> sh) & 7ull);
+        const float *A = s_self + 3 * ia;
+        const float *B = s_atoms[mm] + 3 * ib;
+        const float d0 = s_atoms[mm][15];                         // pair 0: the masked Ca-Ca distance of _dist
+        const float dx = A[0] - B[0], dy = A[1] - B[1], dz = A[2] - B[2];
+        const float D = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz + 1e-6f);  // _get_rbf (:1122); v_sqrt_f32, 1 ulp
+        return p == 0 ? d0 : D;
+    };
+    auto distances = [&]() {
+#if TM_FEAT_DIST2
+        // the two full rounds as one straight-line block (their LDS reads and square roots overlap), then the round of 176
+        const float D0 = dist_one(tid), D1 = dist_one(tid + 512);
+        const int m0 = tid / 25, m1 = (tid + 512) / 25;
+        s_dist[m0][tid - 25 * m0] = D0;
+        s_dist[m1][tid + 512 - 25 * m1] = D1;
+        if (tid < TM_TILE * 25 - 1024) {
+            const int e = tid + 1024, mm = e / 25;
+            s_dist[mm][e - 25 * mm] = dist_one(e);
         }
+#else
+        for (int e = tid; e < TM_TILE * 25; e += 512) {
+            const int mm = e / 25;
+            s_dist[mm][e - 25 * mm] = dist_one(e);
+        }
+#endif
     };
 
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin, cur = 0;
     if (i < tr.end) {
 #if TM_FEAT_DMA
-        fetch_list(i);
-        fetch(i);
-        if (i + tr.step < tr.end) fetch_list(i + tr.step);
+        if (wu == 7) {
+            const int nb = lane < TM_TILE ? lane : TM_TILE - 1;
+            tm_glds4((a.E_idx + (size_t)i * TM_KS) + nb, tm_lds_addr(s_list[0]));
+            landed();
+        }
+        __syncthreads();
+        fetch(i, 0, i + tr.step < tr.end ? i + tr.step : -1);
+        landed();
+        __syncthreads();
 #else
         fetch(i);
 #endif
-        publish(0);
+        publish(0, 0);
         __syncthreads();
         distances();
         __syncthreads();
@@ -768,23 +801,28 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
     for (; i < tr.end; i += tr.step) {
         const int inext = i + tr.step;
         const bool has_next = inext < tr.end;
+#if TM_FEAT_DMA
+        if (tid < TM_TILE * 4) {                                // K columns 400..415: this tile's positional features
+            const int row = tid >> 2, c = tid & 3;
+            store_split<SP, TM_TILE, RBFP_ROWB>(rbf, row, 100 + c, ld4(&s_pos[s_ix[cur][1][row]][4 * c]));
+        }
+        f4 acc[3][1];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = f4{0.f, 0.f, 0.f, 0.f};
+        if (has_next) fetch(inext, cur ^ 1, inext + tr.step < tr.end ? inext + tr.step : -1);   // tile i's list is in s_list[cur]
+#else
         if (tid < TM_TILE * 2 * SP::NP) {                       // zero the K padding (columns 400..415) of every plane row
             const int p = tid / (TM_TILE * 2), rem = tid - p * (TM_TILE * 2);
             *reinterpret_cast<u4 *>(rbf + plane_off8<TM_TILE, RBFP_ROWB>(p, rem >> 1, 50 + (rem & 1))) = u4{0u, 0u, 0u, 0u};
         }
         f4 acc[3][1];
-#if TM_FEAT_DMA
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_ix[cur][1][16 * rb + m] * TM_H + ncol);
-        if (has_next) {
-            fetch(inext);
-            if (inext + tr.step < tr.end) fetch_list(inext + tr.step);
-        }
 #endif
+        // 16 Gaussians per pair, 4 per thread-iteration (:1111-1119). (Measured and dropped in the spill-free kernel: stepping
+        // (row, quad) instead of dividing by 100 — 8 simple ops for 3 integer multiplies, +1.6 %; the v_fma_mix split, nil.)
 #if TM_ABL_NOGAUSS
         if (false)
 #endif
-        for (int e = tid; e < TM_TILE * 100; e += 512) {        // 16 Gaussians per pair, 4 per thread (:1111-1119)
+        for (int e = tid; e < TM_TILE * 100; e += 512) {
             const int mm = e / 100, c = e - mm * 100;
             const float D = s_dist[mm][c >> 2];
             // exp(-((D - mu) / 1.25)^2) = exp2(-(t t)), t = (D - mu) * 0.8 sqrt(log2 e): packed fp32, two centres per op
@@ -798,28 +836,32 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
                 *reinterpret_cast<u2 *>(rbf + plane_off4<TM_TILE, RBFP_ROWB>(p, mm, c)) = u2{lo2[p], hi2[p]};
         }
         mark(0);
-        __syncthreads();                                       // RBF planes complete; s_dist / s_atoms consumed
+#if TM_FEAT_DMA
+        landed();
+#endif
+        __syncthreads();                                       // RBF planes complete; s_dist / s_atoms consumed; DMA pieces in LDS
         mark(1);
 
-        if (!TM_FEAT_DMA) {
-            if (has_next) fetch(inext);
+#if !TM_FEAT_DMA
+        if (has_next) fetch(inext);
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_ix[cur][1][16 * rb + m] * TM_H + ncol);
-        }
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(a.pos_table + s_ix[cur][1][16 * rb + m] * TM_H + ncol);
+#endif
         mma_tile_split<SP, 13, 1, 3, TM_TILE, RBFP_ROWB, 13, 0, true, TM_FEAT_PF>(rbf, wedge, acc, lane);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) row_stats_partial1b(acc[rb][0], &s_stat[16 * rb + m][2 * wv], q);
         mark(2);
-        if (has_next) publish(cur ^ 1);
+        if (has_next) publish(cur ^ 1, cur ^ 1);
         mark(3);
         __syncthreads();                                       // RBF planes dead, statistics + next tile's atoms complete
         mark(4);
+        const f4 g4 = ld4(&s_const[1][ncol]), b4 = ld4(&s_const[2][ncol]);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {                        // norm_edges (:1179)
             const int row = 16 * rb + m;
             float mean, rstd;
             row_stats_finish8b(&s_stat[row][0], mean, rstd);
-            const f4 y = (acc[rb][0] - mean) * rstd * ld4(&s_const[1][ncol]) + ld4(&s_const[2][ncol]);
+            const f4 y = (acc[rb][0] - mean) * rstd * g4 + b4;
             store_split<SP>(tAp, row, c4, y);
             if (a.E_opt) st4(a.E_opt + ((size_t)i * TM_KS + row) * TM_H + ncol, s_ix[cur][0][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
         }
@@ -828,8 +870,9 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
         mark(6);
         __syncthreads();
         mark(7);
+        const f4 be = ld4(&s_const[0][ncol]);
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = ld4(&s_const[0][ncol]);
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = be;
         mma_tile_split<SP, 4, 1>(tAp, we, acc, lane);           // W_e (:1229)
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) st4(tB + chunk_off(16 * rb + m, c4), acc[rb][0]);
@@ -976,7 +1019,7 @@ int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N,
 int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx, const int32_t *cenc,
                      const int32_t *E_idx, const float *D_nb, int64_t T, float *h_E, float *E_opt, hipStream_t st) {
     FeatArgs a;
-    a.edge_w = w->edge_w; a.pos_table = w->pos_table; a.ln_w = w->norm_edges_w; a.ln_b = w->norm_edges_b;
+    a.edge_w = w->edge_w; a.pos_table = w->pos_table; a.pos_w = w->pos_w; a.pos_b = w->pos_b; a.ln_w = w->norm_edges_w; a.ln_b = w->norm_edges_b;
     a.We_w = w->We_w; a.We_b = w->We_b; a.X = X; a.ridx = ridx; a.cenc = cenc; a.E_idx = E_idx; a.D_nb = D_nb;
     a.hE = h_E; a.E_opt = E_opt; a.T = (int)T;
     for (int i = 0; i < 16; ++i)   // torch.linspace(2, 22, 16): double arithmetic, symmetric halves, cast to fp32

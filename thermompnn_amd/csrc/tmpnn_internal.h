@@ -120,7 +120,7 @@ struct TmModeScope {                  // entry points that take a handle open on
     explicit TmModeScope(const tmpnn_weights *w);
     ~TmModeScope();
 };
-int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st, int n_rows = 128, int k_valid = 128);       // tmpnn_split.hip
+int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st, int n_rows = 128, int k_valid = 128, int k_wrap = 0);       // tmpnn_split.hip
 const char *tm_find_wimg(const float *base);                                   // nullptr if no image (or no handle in scope)
 // Non-finite tests under -fno-honor-nans. The kernels are built with relaxed NaN semantics, so hipcc may fold a NaN test
 // on the RESULT of floating-point arithmetic (measured: both the sum test and the exponent-bit test on a computed value

@@ -163,13 +163,14 @@ __device__ __forceinline__ f4 load_joined(const char *tile, int row, int c4) {
 // register-resident weight fragments + the tile GEMM
 // ------------------------------------------------------------------------------------------------
 // Weight fragments of one 16-column block for K = 32*NK32: wf[c].p[plane] = 8 values of
-//   W[(n0 + lane&15) * ld + k0 + 32 c + 8 (lane>>4) + j], j = 0..7.   Columns >= k_valid read as zero (K padding).
+//   W[(n0 + lane&15) * ld + k0 + 32 c + 8 (lane>>4) + j], j = 0..7.   Columns >= k_valid read as zero (K padding), except the
+//   first k_wrap of them, which read the SAME row one `ld` back (W[row, k0 + k - ld]: the featurizer's positional columns).
 template <typename SP>
 struct WFragS { u4 p[SP::NP]; };
 
 template <typename SP, int NK32>
 __device__ __forceinline__ void load_wfrag_split(const float *__restrict__ W, int ld, int n0, int k0, int k_valid,
-                                                 WFragS<SP> (&wf)[NK32], int lane) {
+                                                 WFragS<SP> (&wf)[NK32], int lane, int k_wrap = 0) {
     const float *src = W + (size_t)(n0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4);
 #pragma unroll
     for (int c = 0; c < NK32; ++c) {
@@ -177,7 +178,7 @@ __device__ __forceinline__ void load_wfrag_split(const float *__restrict__ W, in
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int k = 32 * c + 8 * (lane >> 4) + 4 * half;
-            const f4 v = k < k_valid ? ld4(src + 32 * c + 4 * half) : f4{0.f, 0.f, 0.f, 0.f};
+            const f4 v = k < k_valid ? ld4(src + 32 * c + 4 * half) : k < k_valid + k_wrap ? ld4(src + 32 * c + 4 * half - ld) : f4{0.f, 0.f, 0.f, 0.f};
             SP::split2(f2{v.x, v.y}, w[2 * half]);
             SP::split2(f2{v.z, v.w}, w[2 * half + 1]);
         }
