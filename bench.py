@@ -593,7 +593,22 @@ def main():
             dt_ = float(tmax.item())
         return dt_, prof_, ev
 
-    dt, prof, events = timed(args.steps, True, not args.no_profile)
+    # Per-kernel times. Two hipEvent records per launch cost the stream ~2 us each: around all 20 launches of a step that was
+    # 2.7 % of `value` (measured: 2.864 vs 2.787 ms). So: (a) an UN-timed pass with every kernel recorded -> the `kernels`
+    # table and which kernel is dominant; (b) the timed region with events around the dominant kernel's launches only ->
+    # `roofline.achieved` is still measured live inside the timed region, at 0.4 % instead of 2.7 %. (The dominant kernel measures
+    # 2-4 % LONGER there than in pass (a) of the same process, spare records in front of its start event or not: the idle gaps
+    # that 40 records per step open let the clocks recover, so a kernel timed between gaps is faster than the same kernel in
+    # the back-to-back stream that `value` is measured on. Both figures are in `kernels`; rocprofv3's trace opens gaps too.)
+    prof_all, n_all, dom_name = {}, 0, None
+    if not args.no_profile:
+        n_all = max(5, min(args.steps, 20))
+        _, prof_all, _ = timed(n_all, True, True)
+        if prof_all:
+            dom_name = max(prof_all, key=lambda k: prof_all[k][0])
+            lib.tmpnn_profile_select(dom_name.encode())
+    dt, prof, events = timed(args.steps, True, dom_name is not None)
+    lib.tmpnn_profile_select(None)
     eng.check_last_status()                              # a range / max_len problem in the timed work is an error, not a number
     step_spread = spread(events)
 
@@ -641,8 +656,14 @@ def main():
     if rank == 0:
         T = T_loc
         edges = sw["my_edges"] if strong else T * min(48, L)
-        if prof:
-            kern = {k: {"avg_ms": ms / n, "launches": int(n), "total_ms": ms} for k, (ms, n) in prof.items()}
+        if prof_all:
+            kern = {k: {"avg_ms": ms / n, "launches": int(n), "total_ms": ms, "launches_per_step": n / n_all,
+                        "timed": f"un-timed pass of {n_all} steps, every kernel recorded"} for k, (ms, n) in prof_all.items()}
+            if dom_name in prof:                             # the dominant kernel: the timed region's own events
+                ms, n = prof[dom_name]
+                kern[dom_name] = {"avg_ms": ms / n, "launches": int(n), "total_ms": ms, "launches_per_step": n / args.steps,
+                                  "timed": "inside the timed region (the only kernel recorded there)",
+                                  "avg_ms_untimed_pass": prof_all[dom_name][0] / prof_all[dom_name][1]}
             mode = eng.precision
             for k, v in kern.items():
                 f = kernel_flops(k, T, edges)
@@ -653,7 +674,7 @@ def main():
                     v["hbm_GBps"] = by / (v["avg_ms"] * 1e-3) / 1e9
                     rf = kernel_roofs(k, T, edges, v["avg_ms"], mode)
                     v["bound"], v["frac_of_binding_roof"] = rf["bound"], rf["frac"]
-            dom = max(kern, key=lambda k: kern[k]["total_ms"])
+            dom = dom_name
             rf = kernel_roofs(dom, T, edges, kern[dom]["avg_ms"], mode)
             side = rf["hbm"] if rf["bound"] == "hbm" else rf["mfma"]
             if rf["bound"] == "hbm":
@@ -674,9 +695,9 @@ def main():
                           "16-bit matrix cores)" if terms else "the 157.3 TFLOP/s fp32 matrix pipe") +
                          "; `bound` is the roof with the larger time, `frac` is against it"),
                 "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r*_pmc_traffic.json; null when no file was measured on these kernel sources)",
-                "timed_with": "hipEvent pairs on the launch stream inside the timed region"}
+                "timed_with": "hipEvent pairs on the launch stream around this kernel's launches inside the timed region"}
             result["kernels"] = kern
-            per_step = lambda k, v: v["launches"] / args.steps
+            per_step = lambda k, v: v["launches_per_step"]
             total_fl = sum(kernel_flops(k, T, edges) * per_step(k, v) for k, v in kern.items() if kernel_flops(k, T, edges))
             t_roof = 0.0
             for k, v in kern.items():
@@ -689,7 +710,7 @@ def main():
                                   "binding_roof_ms_per_step": t_roof * 1e3,
                                   "note": "frac_of_binding_roof = sum over the launches of a step of max(t_hbm, t_mfma) / measured step time; "
                                           "frac_of_fp32_mfma_peak > 1 means faster than the fp32 matrix pipe could run the algorithmic flops",
-                                  "gpu_kernel_ms_per_step": sum(v["total_ms"] for v in kern.values()) / args.steps}
+                                  "gpu_kernel_ms_per_step": sum(v["avg_ms"] * v["launches_per_step"] for v in kern.values())}
     if rank == 0 and not args.no_extras and not strong:
         result["roofline_gather"] = gather_microbench(eng, device)
         result["roofline_gather"]["traffic"] = pmc_traffic("gather_rows", 16384)

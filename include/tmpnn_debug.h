@@ -20,6 +20,10 @@ extern "C" {
  * returns the number of rows (or a negative error). */
 int tmpnn_profile_enable(int on);
 int tmpnn_profile_fetch(const char **names, double *total_ms, int64_t *launches, int capacity);
+/* Restrict the recording to ONE kernel name (as fetch() reports it; NULL or "" = every kernel again). Two event records
+ * per launch cost the stream ~2 us each: 40 of them in a 20-launch forward are 2.7 % of bench.py's step, 6 around the
+ * three launches of the dominant kernel 0.4 %. */
+int tmpnn_profile_select(const char *name);
 
 /* GEMM core probe: Y[t] = reps x (X[t] W^T) for T tiles of [48,128] and one [128,128] weight; mode 0 = exact fp32 MFMA,
  * mode 1 = six-term bf16x3 split MFMA, mode 2 = three-term f16x2 split MFMA (tmpnn_split.h). For accuracy / speed

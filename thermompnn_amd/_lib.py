@@ -60,6 +60,7 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     "tmpnn_profile_enable": (_i, [_i]),
     "tmpnn_profile_fetch": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), _i]),
+    "tmpnn_profile_select": (_i, [C.c_char_p]),
     "tmpnn_gemm_probe": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
     "tmpnn_clock_probe": (_i, [_i, _i, _p, _p, _p]),
 }

@@ -33,6 +33,8 @@ int tm_check_launch(const char *what) {
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) --------
 struct ProfRec { const char *name; hipEvent_t start, stop; };
 static bool g_prof_on = false;
+static bool g_prof_open = false;               // the launch between the last begin/end is being recorded
+static std::string g_prof_only;                // tmpnn_profile_select: the one kernel to record ("" = all)
 static std::vector<ProfRec> g_prof;            // recorded launches since the last enable/fetch
 static std::vector<hipEvent_t> g_event_pool;   // recycled events
 
@@ -43,15 +45,23 @@ static hipEvent_t prof_event() {
     return e;
 }
 void tm_prof_begin(const char *name, hipStream_t st) {
-    if (!g_prof_on) return;
+    g_prof_open = false;
+    if (!g_prof_on || (!g_prof_only.empty() && g_prof_only != name)) return;
     ProfRec r{name, prof_event(), prof_event()};
     if (!r.start || !r.stop) return;
     (void)hipEventRecord(r.start, st);
     g_prof.push_back(r);
+    g_prof_open = true;
 }
 void tm_prof_end(hipStream_t st) {
-    if (!g_prof_on || g_prof.empty()) return;
+    if (!g_prof_open) return;
     (void)hipEventRecord(g_prof.back().stop, st);
+    g_prof_open = false;
+}
+
+extern "C" int tmpnn_profile_select(const char *name) {
+    g_prof_only = name ? name : "";
+    return TMPNN_OK;
 }
 
 extern "C" int tmpnn_profile_enable(int on) {
