@@ -836,6 +836,50 @@ def _bench(args, env=None, timeout=900):
     return json.loads(lines[0])
 
 
+def test_profile_hook_records_one_kernel_when_asked(engine):
+    """tmpnn_profile_select (include/tmpnn_debug.h): with a name set, ONLY that kernel's launches are bracketed by events —
+    bench.py's timed region uses it for the dominant kernel; without one, every launch is."""
+    import bench
+    from thermompnn_amd import _lib
+    lib = _lib.load()
+    eng = engine
+    b = bench.build_batch(2, 64, 0, torch.device("cuda:0"))
+    fwd = lambda: eng.ssm_forward(b["X"], b["S"], b["mask"], b["ridx"], b["cenc"], b["offsets"], max_len=64)
+    fwd()
+    lib.tmpnn_profile_enable(1)
+    fwd()
+    everything = bench.fetch_profile(lib)
+    lib.tmpnn_profile_enable(0)
+    assert {"knn", "featurize", "enc_msg", "node_update", "enc_edge", "dec_msg", "head"} <= set(everything)
+    assert everything["enc_edge"][1] == 3 and everything["node_update"][1] == 6
+    try:
+        lib.tmpnn_profile_select(b"enc_edge")
+        lib.tmpnn_profile_enable(1)
+        fwd()
+        fwd()
+        only = bench.fetch_profile(lib)
+        lib.tmpnn_profile_enable(0)
+    finally:
+        lib.tmpnn_profile_select(None)
+    assert set(only) == {"enc_edge"} and only["enc_edge"][1] == 6 and only["enc_edge"][0] > 0
+    lib.tmpnn_profile_enable(1)
+    fwd()
+    again = bench.fetch_profile(lib)
+    lib.tmpnn_profile_enable(0)
+    assert set(again) == set(everything)
+
+
+def test_bench_line_times_the_dominant_kernel_inside_the_timed_region():
+    d = _bench(["--steps", "6", "--warmup", "2", "--proteins-per-gpu", "8", "--no-extras", "--no-cpu-baseline"])
+    r, k = d["roofline"], d["kernels"]
+    dom = r["kernel"]
+    assert k[dom]["timed"].startswith("inside the timed region") and k[dom]["launches"] == 6 * k[dom]["launches_per_step"]
+    assert abs(k[dom]["avg_ms"] - r["avg_launch_ms"]) < 1e-12 and r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1
+    assert all(v["timed"].startswith("un-timed pass") for n, v in k.items() if n != dom)
+    assert k[dom]["avg_ms"] * k[dom]["launches_per_step"] >= 0.9 * max(v["avg_ms"] * v["launches_per_step"] for v in k.values())
+    assert d["pipeline"]["gpu_kernel_ms_per_step"] <= d["ms_per_step"] * 1.10      # (event-timed launches include their hand-over)
+
+
 def test_bench_self_launches_and_proves_its_ranks():
     """`python bench.py --gpus 2` with NO launcher around it (the contract command) starts itself under
     torch.distributed.run and echoes what the process group saw: world size, all_reduce(ones), one identity per rank."""
