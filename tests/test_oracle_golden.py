@@ -83,3 +83,28 @@ def test_gap_case_properties():
     # a masked residue appears in no valid row's neighbour list
     valid_rows = g["E_idx"][g["mask"] > 0]
     assert not np.isin(valid_rows, np.nonzero(g["mask"] == 0)[0]).any()
+
+
+def test_hot_tolerance_sits_above_the_reference_own_rounding():
+    """The hot-draw tolerance (conftest.tol_scale) against what it must clear: the distance between the imported reference's own
+    fp32 tensors (the goldens) and a float64 evaluation of the same network (the oracle run in float64 on the same weights). The
+    line is 2.5-7 x that distance for every compared tensor — neither inside the reference's noise nor an order of magnitude
+    loose."""
+    cases = {c: load_golden(c) for c in ("2OCJ_A_hot", "syn_L32_hot")}
+    orig_float, orig_default = torch.Tensor.float, torch.get_default_dtype()
+    torch.Tensor.float = lambda self, *a, **k: self.double()          # the oracle's explicit .float() casts -> float64
+    torch.set_default_dtype(torch.float64)
+    try:
+        for case, g in cases.items():
+            W = {k: v.double() for k, v in weights_for_case(g).items()}
+            X, S, mask, chain_M, ridx, cenc = inputs(g)
+            tr = {}
+            with torch.no_grad():
+                orc.ssm_table(W, X.double(), S, mask.double(), chain_M.double(), ridx, cenc, 48, trace=tr)
+            for key in ("z", "hV_enc3", "hV_dec3", "log_probs"):
+                assert tr[key].dtype == torch.float64
+                ratio = float(np.abs(tr[key][0].numpy() - g[key]).max()) / (TOL_INTERMEDIATE * tol_scale(g, g[key]))
+                assert 0.15 <= ratio <= 0.4, (case, key, ratio)
+    finally:
+        torch.Tensor.float = orig_float
+        torch.set_default_dtype(orig_default)

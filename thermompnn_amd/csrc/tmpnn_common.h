@@ -188,6 +188,11 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
 #endif
     // the library is built with -mno-amdgpu-ieee -fno-honor-nans: fminf / fmaxf are single v_min / v_max (no canonicalising
     // v_max x, x in front of each)
+    // max(x, 0) - |x| 2^e with |x| ITSELF, not the clamped t: v_min / v_max return their finite operand, so a product with t would
+    // launder the NaN / -inf of an f16 overflow into a finite value (DESIGN "Range and precision"). Measured in round 3: the t form
+    // (-t is a modifier of ONE packed fma; here hipcc packs the two fmas and materialises -|x| with a v_or each: 15 instead of 13
+    // VALU per pair) is worth -2 % on the edge update, -0.8 % on the step — not taken, the overflow guarantee goes first; keeping
+    // the two fmas scalar (abs / neg as free source modifiers) trades the 2 v_or for more s_nop behind the v_exp than it saves.
     return f2{fmaf(-fabsf(x.x), __builtin_amdgcn_exp2f(e.x), fmaxf(x.x, 0.f)), fmaf(-fabsf(x.y), __builtin_amdgcn_exp2f(e.y), fmaxf(x.y, 0.f))};
 }
 __device__ __forceinline__ f4 gelu4(f4 v) {
