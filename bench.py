@@ -597,9 +597,10 @@ def main():
     # 2.7 % of `value` (measured: 2.864 vs 2.787 ms). So: (a) an UN-timed pass with every kernel recorded -> the `kernels`
     # table and which kernel is dominant; (b) the timed region with events around the dominant kernel's launches only ->
     # `roofline.achieved` is still measured live inside the timed region, at 0.4 % instead of 2.7 %. (The dominant kernel measures
-    # 2-4 % LONGER there than in pass (a) of the same process, spare records in front of its start event or not: the idle gaps
-    # that 40 records per step open let the clocks recover, so a kernel timed between gaps is faster than the same kernel in
-    # the back-to-back stream that `value` is measured on. Both figures are in `kernels`; rocprofv3's trace opens gaps too.)
+    # 2-4 % LONGER there than in pass (a) of the same process, spare records in front of its start event or not: presumably the
+    # idle gaps that 40 records per step open lower the average power and let the clocks rise, so a kernel timed between gaps is
+    # faster than the same kernel in the back-to-back stream that `value` is measured on. Both figures are in `kernels`;
+    # rocprofv3's trace opens gaps too.)
     prof_all, n_all, dom_name = {}, 0, None
     if not args.no_profile:
         n_all = max(5, min(args.steps, 20))
