@@ -53,7 +53,8 @@ def _kernel_gelu_coefficients():
 
 
 def _gelu_kernel_form(x):
-    """gelu2 in emulated fp32: u = min(|x|, 4 sqrt2); 6 Horner fmas; exp2; max(x, 0) - |x| h (every step rounded to fp32)."""
+    """gelu2 as the f16x2 kernels run it (TM_GELU_NAN3, tmpnn_split.hip), in emulated fp32: t = min(|x|, 4 sqrt2); 6 Horner fmas;
+    exp2; max(x, 0) - t h with the CLAMPED t (every step rounded to fp32)."""
     c = _kernel_gelu_coefficients()
     ax = x.abs()
     t = torch.clamp(ax, max=float(np.float32(5.656854249))).double()
@@ -61,7 +62,7 @@ def _gelu_kernel_form(x):
     for k in c[1:]:
         r = (r * t + float(np.float32(k))).float().double()
     h = torch.exp2(r).float().double()
-    return (-ax.double() * h + torch.clamp(x, min=0).double()).float()
+    return (-t * h + torch.clamp(x, min=0).double()).float()
 
 
 def _run(case, linear, gelu=None):
@@ -110,7 +111,8 @@ def test_a_three_term_bf16_split_would_not_be():
 def test_kernel_gelu_form_is_at_the_fp32_floor():
     """The degree-6 exponent polynomial of gelu2 (fitted to the error of gelu itself, tools/fit_gelu.py) against the exact-erf
     GELU in float64: <= 3e-7 everywhere, i.e. the rounding floor of x Phi(x) in fp32 (2.4e-7 at |x| = 4)."""
-    x = torch.cat([torch.linspace(-8, 8, 400001), torch.randn(200000, generator=torch.Generator().manual_seed(0)) * 1.5]).float()
+    x = torch.cat([torch.linspace(-8, 8, 400001), torch.randn(200000, generator=torch.Generator().manual_seed(0)) * 1.5,
+                   torch.linspace(-300, 300, 60001)]).float()          # far beyond the clamp too (hot-draw Linear outputs reach 2e2)
     want = 0.5 * x.double() * (1.0 + torch.erf(x.double() / np.sqrt(2.0)))
     assert float((_gelu_kernel_form(x).double() - want).abs().max()) <= 3.0e-7
 

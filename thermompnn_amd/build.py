@@ -17,6 +17,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # kernels only (.hip): no sNaN-quieting "v_max x, x" in front of every v_min / v_max (the GELU clamps). Device code never
 # relies on NaNs (range checks test the exponent bits); the host-side PDB reader (.cpp) does and keeps IEEE semantics.
 DEVICE_FLAGS = ["-mno-amdgpu-ieee", "-fno-honor-nans"]
+# ... except the f16x2 per-edge / node kernels (tmpnn_split.hip): their GELU clamps are gfx950's NaN-PROPAGATING v_minimum3_f32 /
+# v_maximum3_f32 (IEEE-754-2019; no canonicalising op in front of them either), which hipcc emits from __builtin_elementwise_minimum /
+# maximum only in a translation unit that honours NaNs (under -fno-honor-nans they degrade to v_min / v_max). See gelu2, TM_GELU_NAN3.
+FILE_FLAGS = {"tmpnn_split.hip": ["-DTM_GELU_NAN3=1"]}
 
 
 def _hipcc() -> str:
@@ -47,7 +51,8 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
             continue
         o = os.path.join(CSRC, os.path.splitext(s)[0] + tag + ".o")
         objs.append(o)
-        cmd = [_hipcc(), *FLAGS, *(DEVICE_FLAGS if s.endswith(".hip") else []), *extra_flags, "-c", os.path.join(CSRC, s), "-o", o]
+        per_file = FILE_FLAGS.get(s, DEVICE_FLAGS if s.endswith(".hip") else [])
+        cmd = [_hipcc(), *FLAGS, *per_file, *extra_flags, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -160,6 +160,9 @@ __device__ __forceinline__ f2 pk_horner(f2 q, f2 t, float c) {
 #ifndef TM_GELU_FORM
 #define TM_GELU_FORM 1
 #endif
+#ifndef TM_GELU_NAN3
+#define TM_GELU_NAN3 0     // 1 (tmpnn_split.hip, built WITH NaN semantics: build.py FILE_FLAGS): NaN-propagating clamps, clamped-t tail
+#endif
 #ifndef TM_ABL_NOGELU
 #define TM_ABL_NOGELU 0
 #endif
@@ -167,7 +170,11 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
 #if TM_ABL_NOGELU
     return x;
 #endif
+#if TM_GELU_NAN3
+    const f2 t = f2{__builtin_elementwise_minimum(fabsf(x.x), 5.656854249f), __builtin_elementwise_minimum(fabsf(x.y), 5.656854249f)};
+#else
     const f2 t = f2{fminf(fabsf(x.x), 5.656854249f), fminf(fabsf(x.y), 5.656854249f)};
+#endif
 #if TM_GELU_FORM == 1
     f2 q = __builtin_elementwise_fma(f2{3.309543916e-05f, 3.309543916e-05f}, t, f2{-7.692427171e-04f, -7.692427171e-04f});
     q = pk_horner(q, t, 8.080792133e-03f);
@@ -188,12 +195,20 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
 #endif
     // the library is built with -mno-amdgpu-ieee -fno-honor-nans: fminf / fmaxf are single v_min / v_max (no canonicalising
     // v_max x, x in front of each)
-    // max(x, 0) - |x| 2^e with |x| ITSELF, not the clamped t: v_min / v_max return their finite operand, so a product with t would
-    // launder the NaN / -inf of an f16 overflow into a finite value (DESIGN "Range and precision"). Measured in round 3: the t form
-    // (-t is a modifier of ONE packed fma; here hipcc packs the two fmas and materialises -|x| with a v_or each: 15 instead of 13
-    // VALU per pair) is worth -2 % on the edge update, -0.8 % on the step — not taken, the overflow guarantee goes first; keeping
-    // the two fmas scalar (abs / neg as free source modifiers) trades the 2 v_or for more s_nop behind the v_exp than it saves.
+#if TM_GELU_NAN3
+    // max(x, 0) - t 2^e with the CLAMPED t as a negated source of ONE packed fma (13 VALU per pair). The clamps are gfx950's
+    // v_minimum3_f32 / v_maximum3_f32: a NaN in x — what an f16 overflow always turns into: h = +-inf and l = -+inf meet in one
+    // accumulator — comes out as NaN (DESIGN "Range and precision"). Beyond the clamp 2^e = Phi(-5.66) = 7.7e-9, so t and |x| differ
+    // by (|x| - 5.66) 7.7e-9 in a result that is 0 or x to that order either way.
+    return __builtin_elementwise_fma(-t, f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)},
+                                     f2{__builtin_elementwise_maximum(x.x, 0.f), __builtin_elementwise_maximum(x.y, 0.f)});
+#else
+    // translation units built with -fno-honor-nans: v_min / v_max return their finite operand, so the last product uses |x| ITSELF —
+    // a product with t would launder the NaN of an f16 overflow into a finite value. hipcc packs the two fmas and materialises -|x|
+    // with a v_or each (15 VALU per pair); keeping them scalar (abs / neg as free source modifiers) costs more s_nop behind the v_exp
+    // than the v_or it saves.
     return f2{fmaf(-fabsf(x.x), __builtin_amdgcn_exp2f(e.x), fmaxf(x.x, 0.f)), fmaf(-fabsf(x.y), __builtin_amdgcn_exp2f(e.y), fmaxf(x.y, 0.f))};
+#endif
 }
 __device__ __forceinline__ f4 gelu4(f4 v) {
     const f2 a = gelu2(f2{v.x, v.y}), b = gelu2(f2{v.z, v.w});
