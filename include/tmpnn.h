@@ -204,6 +204,38 @@ int tmpnn_pdb_num_chains(const tmpnn_pdb_t *p);
 int tmpnn_pdb_fill(const tmpnn_pdb_t *p, float *X, int32_t *S, float *mask, int32_t *residue_idx,
                    int32_t *chain_enc, char *seq, float *ca_mask);
 void tmpnn_pdb_free(tmpnn_pdb_t *p);
+/* The parsed one-letter sequence (NUL-terminated, owned by the handle; same text tmpnn_pdb_fill copies out). */
+const char *tmpnn_pdb_seq(const tmpnn_pdb_t *p);
+/* n parsed structures -> ONE ragged batch in the caller's HOST buffers (pinned staging memory for an async H2D copy),
+ * protein after protein in handle order, on n_threads host threads: offsets [n+1] (always written), then per residue the
+ * arrays of tmpnn_pdb_fill (any may be NULL). capacity = residues the buffers hold; TMPNN_E_WORKSPACE if the batch is
+ * longer. This is tied_featurize's packing (protein_mpnn_utils.py:353-605) for a whole chunk of a many-PDB scan. */
+int tmpnn_pdb_pack_batch(tmpnn_pdb_t *const *handles, int n, int n_threads, int64_t capacity, float *X, int32_t *S,
+                         float *mask, int32_t *residue_idx, int32_t *chain_enc, float *ca_mask, int32_t *offsets);
+
+/* ---- host side: columnar result writer ------------------------------------------------
+ * Replaces the cell-by-cell pandas frame + DataFrame.to_csv of analysis/SSM.py:102-176 (schema 0: ",WT Seq,Model,
+ * Dataset,ddG_pred,position,wildtype,mutation,neighbors,best_AA,pdb") and analysis/custom_inference.py:64,94-111
+ * (schema 1: ",Model,Dataset,ddG_pred,position,wildtype,mutation,pdb,chain"), byte for byte what pandas writes: '\n'
+ * line ends, running index first, floats as repr(float(x)), empty cells for missing values, minimal quoting.
+ * HOST pointers; tables are the [T, ld] fp32 ddG tables of tmpnn_ssm_forward copied back (ld >= 20). */
+typedef struct tmpnn_csv tmpnn_csv_t;
+enum { TMPNN_CSV_PICK_BEST = 1,      /* one row per position carrying best_AA = argmin ddG (SSM.py:32-42,153-162) */
+       TMPNN_CSV_INCLUDE_CYS = 2 };  /* otherwise C is excluded from best_AA / rows mutating to C are dropped (:164-166) */
+int tmpnn_csv_open(const char *path, int schema, tmpnn_csv_t **out);          /* creates the file, writes the header */
+/* Appends the listing of n proteins (may be called once per chunk of a scan; the running index continues). offsets [n+1]
+ * index `table`; seqs[i] (length = rows of protein i; '-' positions are skipped) ; names[i] = 'pdb' cell; neighbors (may be
+ * NULL) [T] -> 'neighbors' cell; `datasets` (may be NULL) per-protein 'Dataset' cells instead of `dataset`; chain: schema 1. */
+int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
+                        const char *const *seqs, const char *const *names, const int32_t *neighbors, const char *model,
+                        const char *dataset, const char *const *datasets, const char *chain, int flags, int n_threads);
+/* Appends an explicit mutation list: triples [m,3] int64 (protein, 0-based position, amino-acid index < 20); schema 0. */
+int tmpnn_csv_write_listed(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
+                           const char *const *seqs, const char *const *names, const int32_t *neighbors, const char *model,
+                           const char *dataset, const int64_t *triples, int64_t m);
+int tmpnn_csv_close(tmpnn_csv_t *c, int64_t *rows_out, int64_t *bytes_out);   /* either may be NULL */
+/* repr(float(v)) into buf (>= 32 bytes, NUL-terminated) -> length: the writer's number format, exposed for tests. */
+int tmpnn_csv_format_double(double v, char *buf);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,20 @@ def _worker(rank, world, port, lengths, q):
         rows = [3, 0] if world == 2 else [1] * world
         got = all_gather_tables(torch.full((rows[rank], 2), float(rank)), rows)
         ok = ok and [g.shape[0] for g in got] == rows and all((g == r).all() for r, g in enumerate(got))
+        # gather-to-root (what the CLI uses: only rank 0 writes), same ragged case incl. the empty shard
+        from thermompnn_amd.dist import gather_tables_root
+        root = gather_tables_root(torch.full((rows[rank], 2), float(rank)), rows)
+        if rank == 0:
+            ok = ok and [g.shape[0] for g in root] == rows and all((g == r).all() for r, g in enumerate(root))
+        else:
+            ok = ok and root is None
+        t_root = scan_sharded(lengths, compute, gather="root")
+        mine = partition_proteins(lengths, world)[rank]
+        if rank == 0:
+            ok = ok and all(torch.equal(t, fake_table(i, lengths[i])) for i, t in enumerate(t_root))
+        else:
+            ok = ok and all((t is not None) == (i in mine) for i, t in enumerate(t_root))
+        seen[:] = seen[:len(seen) // 2]                    # (the second scan computed the same shard again)
         q.put((rank, ok, sorted(seen)))
     finally:
         dist.destroy_process_group()
@@ -90,6 +104,44 @@ def test_sharded_parse_reads_each_file_where_it_is_needed(tmp_path):
     # a world of one parses everything once
     prots, lengths, seqs, names = parse_sharded(paths, ["A"] * 6)
     assert all(p is not None for p in prots) and lengths == [len(p["S"]) for p in full]
+
+
+def _bad_file_worker(rank, world, port, paths, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from thermompnn_amd.dist import parse_sharded
+        try:
+            parse_sharded(paths, ["A"] * len(paths))
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_parse_fails_on_every_rank_when_one_file_is_corrupt(tmp_path):
+    """a malformed file is read by ONE rank only (strided pre-pass); the error must reach every rank through the
+    same collective instead of leaving the others blocked until the backend's timeout."""
+    import shutil
+    from conftest import GOLDEN
+    paths = []
+    for k in range(4):
+        dst = str(tmp_path / f"p{k}.pdb")
+        shutil.copy(os.path.join(GOLDEN, "2OCJ.pdb"), dst)
+        paths.append(dst)
+    (tmp_path / "p1.pdb").write_text("ATOM      1  N   ALA A   1      xx.000   0.000   0.000\n")      # rank 1's stride
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bad_file_worker, args=(r, 2, port, paths, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("rank 1" in msg and "malformed" in msg for _, msg in results), results
 
 
 def _free_port():

@@ -1,0 +1,152 @@
+"""PDB files -> ddG tables -> CSV / binary at engine speed: the three-stage host
+pipeline (thermompnn_amd/pipeline.py) and the native columnar writer against the per-protein, per-row reference-shaped path."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine(synthetic_weights):
+    from thermompnn_amd.engine import Engine
+    return Engine(synthetic_weights, "cuda:0", 48)
+
+
+def _pdb_set(tmp_path, n=23, seed=11):
+    from thermompnn_amd.synthetic import backbone_pdb_text, synthetic_backbone
+    rng = np.random.default_rng(seed)
+    paths = []
+    for i, L in enumerate(rng.integers(20, 200, size=n)):
+        X, seq = synthetic_backbone(int(L), 9000 + i)
+        p = tmp_path / f"syn_{i:03d}.pdb"
+        p.write_text(backbone_pdb_text(X, seq))
+        paths.append(str(p))
+    paths.insert(3, os.path.join(GOLDEN, "2OCJ.pdb"))
+    paths.insert(9, os.path.join(GOLDEN, "2OCJ_gap_chainA.pdb"))     # numbering gaps + a residue without its N atom
+    return paths
+
+
+def _reference_shaped_rows(engine, paths, centrality, pick_best, include_cys):
+    """One protein per forward, one dict per row: the shape of analysis/SSM.py:105-166 on the same engine."""
+    from thermompnn_amd import native_pdb, ssm_scan
+    rows, tables = [], []
+    for path in paths:
+        p = native_pdb.parse_pdb(path, "A")
+        L = len(p["seq"])
+        off = torch.tensor([0, L], dtype=torch.int32)
+        t = engine.ssm_forward(p["X"], p["S"], p["mask"], p["residue_idx"], p["chain_enc"], off)["ddg"].cpu().numpy()
+        nb = engine.centrality(p["X"], p["ca_mask"], off).cpu().numpy() if centrality else None
+        tables.append(t)
+        rows += ssm_scan.rows_for_protein(p, t, nb, "ThermoMPNN", "custom", pick_best, include_cys)
+    return rows, tables
+
+
+@pytest.mark.parametrize("centrality,pick_best,include_cys", [(False, False, False), (True, True, False), (True, False, True)])
+def test_pipeline_csv_is_byte_identical_to_the_row_writer(tmp_path, engine, centrality, pick_best, include_cys):
+    from thermompnn_amd import ssm_scan
+    paths = _pdb_set(tmp_path)
+    rows, _ = _reference_shaped_rows(engine, paths, centrality, pick_best, include_cys)
+    ssm_scan.write_csv(rows, str(tmp_path / "rows.csv"))
+    out = str(tmp_path / "pipe.csv")
+    # 7 files per chunk, at most 600 residues per forward: chunks split, several slots in flight, the running index continues
+    n, stats = ssm_scan.scan_to_file(engine, paths, ["A"] * len(paths), out, pick_best=pick_best, include_cys=include_cys,
+                                     centrality=centrality, chunk_files=7, chunk_residues=600, parse_threads=3)
+    assert n == len(rows) and stats.files == len(paths) and stats.chunks >= 4 and stats.reruns == 0
+    assert open(out, "rb").read() == (tmp_path / "rows.csv").read_bytes()
+
+
+def test_pipeline_binary_output_and_cli(tmp_path, engine):
+    from thermompnn_amd import native_pdb, ssm_scan
+    paths = _pdb_set(tmp_path, n=9, seed=5)
+    _, tables = _reference_shaped_rows(engine, paths, False, False, False)
+    out = str(tmp_path / "scan.npz")
+    n, stats = ssm_scan.scan_to_file(engine, paths, ["A"] * len(paths), out, centrality=True, chunk_files=4)
+    z = np.load(out)
+    assert n == z["ddg"].shape[0] == sum(t.shape[0] for t in tables) and list(z["offsets"]) == list(np.concatenate([[0], np.cumsum([t.shape[0] for t in tables])]))
+    np.testing.assert_array_equal(z["ddg"], np.concatenate(tables))                 # ragged chunks == single forwards, bit for bit
+    assert list(z["names"]) == [os.path.basename(p)[:-4] for p in paths]
+    assert list(z["seqs"]) == [native_pdb.parse_pdb(p, "A")["seq"] for p in paths] and z["neighbors"].shape == (n,)
+    # the CLI, CSV and binary, equals the library call
+    csv_cli = ssm_scan.main(paths + ["--synthetic_weights", "0", "--out", str(tmp_path / "cli.csv"), "--chunk_files", "3"])
+    ssm_scan.scan_to_file(engine, paths, ["A"] * len(paths), str(tmp_path / "lib.csv"))
+    assert open(csv_cli, "rb").read() == (tmp_path / "lib.csv").read_bytes()
+    npz_cli = ssm_scan.main(paths + ["--synthetic_weights", "0", "--out", str(tmp_path / "cli.npz")])
+    np.testing.assert_array_equal(np.load(npz_cli)["ddg"], z["ddg"])
+    # an unreadable file stops the scan with the parser's message (no hang, no partial silence)
+    from thermompnn_amd._lib import TmpnnError
+    with pytest.raises(TmpnnError, match="cannot open"):
+        ssm_scan.scan_to_file(engine, paths[:5] + [str(tmp_path / "missing.pdb")] + paths[5:], ["A"] * (len(paths) + 1),
+                              str(tmp_path / "bad.csv"), chunk_files=2)
+    assert ssm_scan.scan_to_file(engine, [], [], str(tmp_path / "empty.csv"))[0] == 0
+
+
+def test_pipeline_reruns_an_overflowing_chunk(tmp_path, synthetic_weights):
+    """A chunk whose f16x2 forward leaves the fp16 range is rerun at the retry precision from its staging slot (the writer
+    thread sees the chunk's status word): same tables as a bf16x3 engine, with a warning; no retry precision -> error."""
+    from thermompnn_amd import ssm_scan
+    from thermompnn_amd._lib import TmpnnRangeError
+    from thermompnn_amd.engine import Engine
+    W = {k: v.clone() for k, v in synthetic_weights.items()}
+    W["prot_mpnn.features.edge_embedding.weight"] = W["prot_mpnn.features.edge_embedding.weight"] * 1e6
+    paths = _pdb_set(tmp_path, n=6, seed=3)
+    ch = ["A"] * len(paths)
+    ssm_scan.scan_to_file(Engine(W, "cuda:0", 48, precision="bf16x3"), paths, ch, str(tmp_path / "want.npz"), chunk_files=3)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        _, stats = ssm_scan.scan_to_file(Engine(W, "cuda:0", 48, precision="f16x2"), paths, ch, str(tmp_path / "got.npz"), chunk_files=3)
+    assert stats.reruns == stats.chunks >= 2 and any("bf16x3" in str(w.message) for w in rec)
+    np.testing.assert_array_equal(np.load(tmp_path / "got.npz")["ddg"], np.load(tmp_path / "want.npz")["ddg"])
+    with pytest.raises(TmpnnRangeError):
+        ssm_scan.scan_to_file(Engine(W, "cuda:0", 48, precision="f16x2", retry_precision=None), paths, ch,
+                              str(tmp_path / "strict.npz"), chunk_files=3)
+
+
+def test_custom_inference_fast_path_equals_the_reference_shaped_path(tmp_path):
+    """custom_inference: native parser + one forward + native writer == TransferModel.forward(pdb, mutations) with one
+    Mutation / result dict per mutant + csv.writer (analysis/custom_inference.py:72-111), byte for byte."""
+    from thermompnn_amd import custom_inference
+    pdb = os.path.join(GOLDEN, "2OCJ.pdb")
+    os.makedirs(tmp_path / "a")
+    os.makedirs(tmp_path / "b")
+    fast = custom_inference.main(["--pdb", pdb, "--chain", "A", "--synthetic_weights", "0", "--out_dir", str(tmp_path / "a")])
+    slow = custom_inference.main(["--pdb", pdb, "--chain", "A", "--synthetic_weights", "0", "--out_dir", str(tmp_path / "b"),
+                                  "--reference_shaped"])
+    a, b = open(fast, "rb").read(), open(slow, "rb").read()
+    assert a == b and a.startswith(b",Model,Dataset,ddG_pred,position,wildtype,mutation,pdb,chain\n0,ThermoMPNN,2OCJ,")
+    assert a.count(b"\n") == 3881
+
+
+def test_sharded_file_scan_two_ranks_one_device(tmp_path):
+    """The many-PDB CLI under torchrun (2 ranks on cuda:0, gloo): every rank runs the pipeline on its LPT shard, one gather to
+    rank 0, same bytes as the single-process streaming run — CSV with post-processing and the binary tables."""
+    import subprocess
+    import sys
+    from test_gpu_parity import _torchrun
+    from thermompnn_amd import ssm_scan
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    paths = _pdb_set(tmp_path, n=10, seed=21)
+    flags = ["--synthetic_weights", "0", "--centrality", "--pick_best", "--chunk_files", "3"]
+    one = ssm_scan.main(paths + flags + ["--out", str(tmp_path / "one.csv")])
+    r = _torchrun(["-m", "thermompnn_amd.ssm_scan"] + paths + flags + ["--out", str(tmp_path / "two.csv")],
+                  {"TMPNN_ONE_DEVICE": "1", "PYTHONPATH": repo})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    assert open(one, "rb").read() == (tmp_path / "two.csv").read_bytes()
+    r = _torchrun(["-m", "thermompnn_amd.ssm_scan"] + paths + ["--synthetic_weights", "0", "--out", str(tmp_path / "two.npz")],
+                  {"TMPNN_ONE_DEVICE": "1", "PYTHONPATH": repo})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    one_npz = ssm_scan.main(paths + ["--synthetic_weights", "0", "--out", str(tmp_path / "one.npz")])
+    a, b = np.load(one_npz), np.load(tmp_path / "two.npz")
+    np.testing.assert_array_equal(a["ddg"], b["ddg"])
+    assert list(a["names"]) == list(b["names"]) and list(a["offsets"]) == list(b["offsets"])
+    # a corrupt file fails BOTH ranks promptly (no rank may be left waiting in a collective)
+    bad = tmp_path / "bad.pdb"
+    bad.write_text("ATOM      1  N   ALA A   1      xx.000   0.000   0.000\n")
+    r = _torchrun(["-m", "thermompnn_amd.ssm_scan"] + paths[:3] + [str(bad)] + ["--synthetic_weights", "0", "--out", str(tmp_path / "x.csv")],
+                  {"TMPNN_ONE_DEVICE": "1", "PYTHONPATH": repo}, timeout=300)
+    assert r.returncode != 0 and "malformed" in (r.stdout + r.stderr)

@@ -438,3 +438,130 @@ def test_native_parser_survives_malformed_input(tmp_path):
     # the span guard: one chain whose residue numbers cover the whole 5-column range is an error, not a 110 000-row allocation
     span = [f for f in files if f.endswith("hand_resnum_span.pdb")][0]
     assert lines[files.index(span)].split()[0] in ("0", "-1")
+
+
+def test_native_csv_number_format_is_python_repr():
+    """The ddG_pred cell is what pandas writes for a Python float: repr(float(x)) — shortest round-trip digits of the double,
+    fixed notation for 1e-4 <= |x| < 1e16, else exponent form with a two-digit exponent (examples/ThermoMPNN_inference_2OCJ.csv)."""
+    from thermompnn_amd import native_csv
+    rng = np.random.default_rng(0)
+    vals = [float(v) for v in rng.normal(size=3000).astype(np.float32)]
+    vals += [float(v) for v in rng.integers(0, 2 ** 32, size=20000, dtype=np.uint64).astype(np.uint32).view(np.float32)]
+    vals += [0.0, -0.0, 1.0, -2.0, 1e-5, 1e-4, 9.9999e-5, 1e15, 1e16, 9999999999999998.0, 1.2345e22, 5e-324, 1.7976931348623157e308,
+             float("inf"), float("-inf"), float(np.float32(0.1)), 100.0, 123456.789, -0.040876448154449463]
+    for v in vals:
+        assert native_csv.format_double(v) == repr(v), (v, native_csv.format_double(v))
+    assert native_csv.format_double(float("nan")) == "nan"
+
+
+def _random_scan(rng, n=24):
+    seqs, tabs, nbs, names = [], [], [], []
+    for i in range(n):
+        L = int(rng.integers(1, 120))
+        s = [AA20[k] for k in rng.integers(0, 20, L)]
+        for k in rng.integers(0, L, 2):
+            s[k] = "-"
+        seqs.append("".join(s))
+        tabs.append(rng.normal(scale=3.0, size=(L, 21)).astype(np.float32))
+        nbs.append(rng.integers(-1, 40, L).astype(np.int32))
+        names.append(f"prot_{i}")
+    names[3], names[5] = 'odd,"name', "d.p1abc.pdb"                # quoting; the reference's character-set strip of '.pdb'
+    tabs[2][0, 3] = tabs[2][0, 9] = -50.0                           # an exact tie for best_AA: first minimum wins
+    return seqs, tabs, nbs, names
+
+
+AA20 = "ACDEFGHIKLMNPQRSTVWY"
+
+
+@pytest.mark.parametrize("pick,cys,use_nb", [(False, False, False), (False, True, True), (True, False, True), (True, True, False)])
+def test_native_csv_writer_equals_row_writer(tmp_path, pick, cys, use_nb):
+    """csrc/tmpnn_csv.cpp == rows_for_protein + csv.writer, byte for byte, in every post-processing mode (SSM.py:128-176);
+    written in two chunks so the running index continues across calls."""
+    from thermompnn_amd import native_csv, ssm_scan
+    seqs, tabs, nbs, names = _random_scan(np.random.default_rng(7))
+    rows = []
+    for i in range(len(seqs)):
+        rows += ssm_scan.rows_for_protein({"seq": seqs[i], "name": names[i]}, tabs[i], nbs[i] if use_nb else None, "ThermoMPNN",
+                                          "my,set", pick, cys)
+    ssm_scan.write_csv(rows, str(tmp_path / "py.csv"))
+    table = np.concatenate(tabs)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int32)
+    nb = np.concatenate(nbs)
+    stripped = [n.strip(".pdb") for n in names]
+    w = native_csv.CsvWriter(str(tmp_path / "nat.csv"))
+    cut = 9
+    w.write_ssm(table[:off[cut]], off[:cut + 1], seqs[:cut], stripped[:cut], nb[:off[cut]] if use_nb else None, dataset="my,set",
+                pick_best=pick, include_cys=cys, n_threads=3)
+    w.write_ssm(table[off[cut]:], off[cut:] - off[cut], seqs[cut:], stripped[cut:], nb[off[cut]:] if use_nb else None,
+                dataset="my,set", pick_best=pick, include_cys=cys, n_threads=3)
+    assert w.close() == len(rows)
+    a, b = (tmp_path / "py.csv").read_bytes(), (tmp_path / "nat.csv").read_bytes()
+    assert a == b and w.bytes == len(a) and b"\r" not in a
+    # the one-call form used after a multi-rank gather
+    res = dict(table=table, offsets=off, seqs=seqs, names=names, neighbors=nb if use_nb else None)
+    assert ssm_scan.write_scan_csv(str(tmp_path / "one.csv"), res, "ThermoMPNN", "my,set", pick, cys) == len(rows)
+    assert (tmp_path / "one.csv").read_bytes() == a
+
+
+def test_native_csv_listed_and_custom_inference_schema(tmp_path):
+    from thermompnn_amd import custom_inference, native_csv, ssm_scan
+    from thermompnn_amd._lib import TmpnnError
+    seqs, tabs, nbs, names = _random_scan(np.random.default_rng(8), 6)
+    table = np.concatenate(tabs)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int32)
+    # explicit mutation list (BASELINE config 4 / --mutations)
+    rng = np.random.default_rng(9)
+    tri = []
+    for _ in range(300):
+        i = int(rng.integers(0, 6))
+        pos = int(rng.integers(0, len(seqs[i])))
+        if seqs[i][pos] != "-":
+            tri.append((i, pos, int(rng.integers(0, 20))))
+    rows = [{"WT Seq": seqs[i], "Model": "ThermoMPNN", "Dataset": "custom", "ddG_pred": float(tabs[i][pos, a]), "position": pos,
+             "wildtype": seqs[i][pos], "mutation": AA20[a], "neighbors": int(nbs[i][pos]), "best_AA": "", "pdb": names[i].strip(".pdb")}
+            for i, pos, a in tri]
+    ssm_scan.write_csv(rows, str(tmp_path / "py.csv"))
+    res = dict(table=table, offsets=off, seqs=seqs, names=names, neighbors=np.concatenate(nbs))
+    assert ssm_scan.write_scan_csv(str(tmp_path / "nat.csv"), res, "ThermoMPNN", "custom", False, False, np.array(tri)) == len(tri)
+    assert (tmp_path / "py.csv").read_bytes() == (tmp_path / "nat.csv").read_bytes()
+    with pytest.raises(TmpnnError, match="out of range"):
+        ssm_scan.write_scan_csv(str(tmp_path / "bad.csv"), res, "ThermoMPNN", "custom", False, False, np.array([[0, 10 ** 6, 0]]))
+    # custom_inference layout (examples/ThermoMPNN_inference_2OCJ.csv:1)
+    i = 1
+    rows = [{"Model": "ThermoMPNN", "Dataset": "2OCJ", "ddG_pred": float(tabs[i][pos, a]), "position": pos, "wildtype": wt,
+             "mutation": AA20[a], "pdb": "2OCJ", "chain": "A"} for pos, wt in enumerate(seqs[i]) if wt != "-" for a in range(20)]
+    custom_inference.write_csv(rows, str(tmp_path / "ci_py.csv"))
+    with native_csv.CsvWriter(str(tmp_path / "ci_nat.csv"), native_csv.SCHEMA_CUSTOM_INFERENCE) as w:
+        w.write_ssm(tabs[i], np.array([0, len(seqs[i])], np.int32), [seqs[i]], ["2OCJ"], dataset="2OCJ", chain="A", include_cys=True)
+    assert (tmp_path / "ci_py.csv").read_bytes() == (tmp_path / "ci_nat.csv").read_bytes()
+    with pytest.raises(TmpnnError, match="sequence length"):
+        with native_csv.CsvWriter(str(tmp_path / "x.csv")) as w:
+            w.write_ssm(tabs[0], np.array([0, len(seqs[0])], np.int32), [seqs[0] + "A"], ["x"])
+    with pytest.raises(TmpnnError, match="cannot create"):
+        native_csv.CsvWriter(str(tmp_path / "no_such_dir" / "x.csv"))
+
+
+def test_native_pack_batch_equals_per_file_fill():
+    """tmpnn_pdb_pack_batch (the pipeline's staging step) == tmpnn_pdb_fill protein after protein, offsets included."""
+    import ctypes as C
+    from thermompnn_amd import _lib, native_pdb
+    lib = _lib.load()
+    paths, chains = [PDB, GAP, PDB], ["A", "A", "AB"]
+    single = native_pdb.parse_pdbs(paths, chains)
+    n = len(paths)
+    hs = (C.c_void_p * n)()
+    cp = (C.c_char_p * n)(*[p.encode() for p in paths])
+    cc = (C.c_char_p * n)(*[c.encode() for c in chains])
+    _lib.check(lib.tmpnn_pdb_parse_batch(cp, cc, n, 2, hs))
+    T = sum(len(s["S"]) for s in single)
+    X, S, mask = np.full((T, 4, 3), -1, np.float32), np.full(T, -1, np.int32), np.full(T, -1, np.float32)
+    ridx, cenc, ca, off = np.full(T, -1, np.int32), np.full(T, -1, np.int32), np.full(T, -1, np.float32), np.zeros(n + 1, np.int32)
+    p = lambda a: a.ctypes.data
+    assert lib.tmpnn_pdb_pack_batch(hs, n, 2, T - 1, p(X), p(S), p(mask), p(ridx), p(cenc), p(ca), p(off)) == -4   # TMPNN_E_WORKSPACE
+    _lib.check(lib.tmpnn_pdb_pack_batch(hs, n, 2, T, p(X), p(S), p(mask), p(ridx), p(cenc), p(ca), p(off)))
+    assert off.tolist() == np.concatenate([[0], np.cumsum([len(s["S"]) for s in single])]).tolist()
+    for k, want in (("X", X), ("S", S), ("mask", mask), ("residue_idx", ridx), ("chain_enc", cenc), ("ca_mask", ca)):
+        np.testing.assert_array_equal(np.concatenate([s[k] for s in single]), want)
+    assert [C.string_at(lib.tmpnn_pdb_seq(C.c_void_p(h))).decode() for h in hs] == [s["seq"] for s in single]
+    for h in hs:
+        lib.tmpnn_pdb_free(C.c_void_p(h))

@@ -1,0 +1,323 @@
+// Columnar result writer (host C++). The reference appends to a pandas frame cell by cell with one
+// device sync per value and lets DataFrame.to_csv format it (/root/reference/analysis/SSM.py:128-176,
+// analysis/custom_inference.py:94-111); at engine speed (10^8 predictions/s) the writer is the bottleneck, so this formats the
+// gathered [T, 21] ddG table straight into the reference's two CSV layouts:
+//   schema 0 (SSM.py:102-103,176):              ,WT Seq,Model,Dataset,ddG_pred,position,wildtype,mutation,neighbors,best_AA,pdb
+//   schema 1 (custom_inference.py:64,96-111):   ,Model,Dataset,ddG_pred,position,wildtype,mutation,pdb,chain
+// byte for byte what pandas writes: '\n' line ends, the unnamed running index first, floats as repr(float(x)) (shortest
+// round-trip digits of the DOUBLE the fp32 value converts to, Python's fixed / exponent switch), empty cells for missing
+// values, minimal quoting. Proteins are formatted by a pool of host threads, each into its own buffer; buffers are
+// committed in protein order (a ticket hands out the file offset) and written with pwrite outside the lock, so formatting
+// and the page-cache copies of different proteins overlap and memory stays at one protein per thread.
+#include <errno.h>
+#include <fcntl.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tmpnn.h"
+int tm_set_error(int code, const char *fmt, ...);
+
+namespace {
+
+const char kAA20[21] = "ACDEFGHIKLMNPQRSTVWY";        // ALPHABET[:-1], datasets.py:13
+
+// repr(float) of CPython (float_repr_style 'short', format code 'r'): shortest digits that round-trip, fixed notation when
+// -4 <= exponent < 16, else d[.ddd]e+XX. -> number of chars written (at most 25).
+inline int repr_double(double v, char *out) {
+    if (v != v) { memcpy(out, "nan", 3); return 3; }
+    char *o = out;
+    if (std::signbit(v)) { *o++ = '-'; v = -v; }
+    if (v == INFINITY) { memcpy(o, "inf", 3); return (int)(o - out) + 3; }
+    if (v == 0.0) { memcpy(o, "0.0", 3); return (int)(o - out) + 3; }
+    char sci[40];
+    const std::to_chars_result r = std::to_chars(sci, sci + sizeof(sci), v, std::chars_format::scientific);
+    // sci = d[.ddd]e[+-]XX
+    char digits[24];
+    int nd = 0;
+    const char *q = sci;
+    for (; q < r.ptr && *q != 'e'; ++q)
+        if (*q != '.') digits[nd++] = *q;
+    ++q;                                                         // 'e'
+    const bool eneg = *q == '-';
+    ++q;
+    int ex = 0;
+    for (; q < r.ptr; ++q) ex = ex * 10 + (*q - '0');
+    if (eneg) ex = -ex;
+    const int decpt = ex + 1;                                    // digits[0..decpt) are the integer part
+    if (decpt > -4 && decpt <= 16) {
+        if (decpt <= 0) {
+            *o++ = '0'; *o++ = '.';
+            for (int i = 0; i < -decpt; ++i) *o++ = '0';
+            memcpy(o, digits, nd); o += nd;
+        } else if (decpt >= nd) {
+            memcpy(o, digits, nd); o += nd;
+            for (int i = nd; i < decpt; ++i) *o++ = '0';
+            *o++ = '.'; *o++ = '0';
+        } else {
+            memcpy(o, digits, decpt); o += decpt;
+            *o++ = '.';
+            memcpy(o, digits + decpt, nd - decpt); o += nd - decpt;
+        }
+    } else {
+        *o++ = digits[0];
+        if (nd > 1) { *o++ = '.'; memcpy(o, digits + 1, nd - 1); o += nd - 1; }
+        *o++ = 'e';
+        *o++ = ex < 0 ? '-' : '+';
+        int a = ex < 0 ? -ex : ex;
+        char t[8]; int nt = 0;
+        do { t[nt++] = (char)('0' + a % 10); a /= 10; } while (a);
+        if (nt < 2) t[nt++] = '0';
+        while (nt) *o++ = t[--nt];
+    }
+    return (int)(o - out);
+}
+
+inline char *put_int(char *o, int64_t v) {
+    if (v < 0) { *o++ = '-'; v = -v; }
+    char t[24]; int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *o++ = t[--n];
+    return o;
+}
+
+// csv QUOTE_MINIMAL (what both csv.writer and pandas do): quote a field that holds the delimiter, a quote or a line break
+std::string csv_field(const char *s) {
+    const std::string f = s ? s : "";
+    if (f.find_first_of(",\"\r\n") == std::string::npos) return f;
+    std::string q = "\"";
+    for (char c : f) { if (c == '"') q.push_back('"'); q.push_back(c); }
+    q.push_back('"');
+    return q;
+}
+
+}  // namespace
+
+struct tmpnn_csv {
+    int fd = -1;
+    int schema = 0;
+    int64_t rows = 0;          // data rows written so far = the next running index
+    int64_t bytes = 0;         // file offset of the next byte
+    std::string path;
+};
+
+static bool write_all_at(int fd, const char *p, size_t n, int64_t off) {
+    while (n) {
+        const ssize_t w = pwrite(fd, p, n, (off_t)off);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; n -= (size_t)w; off += w;
+    }
+    return true;
+}
+
+extern "C" int tmpnn_csv_open(const char *path, int schema, tmpnn_csv_t **out) {
+    if (!path || !out || schema < 0 || schema > 1) return tm_set_error(TMPNN_E_INVALID, "csv_open: bad argument");
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (fd < 0) return tm_set_error(TMPNN_E_INVALID, "csv_open: cannot create %s: %s", path, strerror(errno));
+    const char *hdr = schema == 0 ? ",WT Seq,Model,Dataset,ddG_pred,position,wildtype,mutation,neighbors,best_AA,pdb\n"
+                                  : ",Model,Dataset,ddG_pred,position,wildtype,mutation,pdb,chain\n";
+    tmpnn_csv *c = new tmpnn_csv();
+    c->fd = fd; c->schema = schema; c->path = path;
+    if (!write_all_at(fd, hdr, strlen(hdr), 0)) {
+        close(fd); delete c;
+        return tm_set_error(TMPNN_E_INVALID, "csv_open: write to %s failed: %s", path, strerror(errno));
+    }
+    c->bytes = (int64_t)strlen(hdr);
+    *out = c;
+    return TMPNN_OK;
+}
+
+extern "C" int tmpnn_csv_close(tmpnn_csv_t *c, int64_t *rows_out, int64_t *bytes_out) {
+    if (!c) return tm_set_error(TMPNN_E_INVALID, "csv_close: null handle");
+    if (rows_out) *rows_out = c->rows;
+    if (bytes_out) *bytes_out = c->bytes;
+    const int rc = close(c->fd);
+    const std::string path = c->path;
+    delete c;
+    if (rc != 0) return tm_set_error(TMPNN_E_INVALID, "csv_close: %s: %s", path.c_str(), strerror(errno));
+    return TMPNN_OK;
+}
+
+// The full site-saturation listing of n proteins (SSM.py:128-166 / custom_inference.py:94-111).
+//   table [T, ld] fp32 HOST (ld >= 20; columns 0..19 = ddG of mutating to ALPHABET[a]); offsets [n+1] int32 rows of `table`;
+//   seqs[i] = parsed sequence of protein i ('-' positions are skipped: the reference's None mutations); names[i] = the 'pdb'
+//   cell; neighbors (may be NULL) [T] int32 -> 'neighbors' cell (schema 0); datasets (may be NULL: `dataset` for all) per
+//   protein 'Dataset' cells; chain = schema 1's last cell.
+//   flags: TMPNN_CSV_PICK_BEST = one row per position (mutation 'A', drop_duplicates keep='first') carrying best_AA = argmin
+//   ddG (first minimum; C excluded unless TMPNN_CSV_INCLUDE_CYS); without PICK_BEST, rows mutating to C are dropped unless
+//   INCLUDE_CYS (SSM.py:153-166). Both schemas honour the flags; the custom_inference layout is written with INCLUDE_CYS
+//   (that script lists all 20 mutants).
+extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
+                                   const char *const *seqs, const char *const *names, const int32_t *neighbors,
+                                   const char *model, const char *dataset, const char *const *datasets, const char *chain,
+                                   int flags, int n_threads) {
+    if (!c || !offsets || n < 0 || ld < 20 || (n > 0 && (!table || !seqs || !names)))
+        return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: bad argument");
+    const bool pick = flags & TMPNN_CSV_PICK_BEST, cys = flags & TMPNN_CSV_INCLUDE_CYS;
+    const int schema = c->schema;
+    // running index of every protein's first row
+    std::vector<int64_t> first((size_t)n + 1);
+    first[0] = c->rows;
+    for (int i = 0; i < n; ++i) {
+        const int32_t L = offsets[i + 1] - offsets[i];
+        if (L < 0 || !seqs[i] || (int64_t)strlen(seqs[i]) != L)
+            return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: protein %d: sequence length does not match its %d table rows", i, L);
+        int64_t npos = 0;
+        for (int32_t k = 0; k < L; ++k) npos += seqs[i][k] != '-';
+        first[i + 1] = first[i] + npos * (pick ? 1 : (cys ? 20 : 19));
+    }
+    const std::string f_model = csv_field(model), f_chain = csv_field(chain);
+    std::atomic<int> next(0);
+    std::atomic<bool> failed(false);
+    std::mutex mu;
+    std::condition_variable cv;
+    int commit = 0;                       // next protein allowed to take its file offset
+    int64_t off = c->bytes;
+    auto work = [&]() {
+        std::vector<char> buf;
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            const char *seq = seqs[i];
+            const int32_t L = offsets[i + 1] - offsets[i];
+            const float *tab = table + (size_t)offsets[i] * ld;
+            const int32_t *nb = neighbors ? neighbors + offsets[i] : nullptr;
+            const std::string f_name = csv_field(names[i]);
+            const std::string f_data = csv_field(datasets ? datasets[i] : dataset);
+            // the cells between the running index and the ddG value, and after the per-row cells
+            std::string head = ",";
+            if (schema == 0) { head += csv_field(seq); head += ","; }
+            head += f_model; head += ","; head += f_data; head += ",";
+            const int64_t nrows = first[i + 1] - first[i];
+            const size_t per_row = 20 + head.size() + 26 + 12 + 4 + 12 + 2 + f_name.size() + f_chain.size() + 4;
+            buf.resize((size_t)nrows * per_row + 64);
+            char *o = buf.data();
+            int64_t row = first[i];
+            for (int32_t pos = 0; pos < L; ++pos) {
+                const char wt = seq[pos];
+                if (wt == '-') continue;
+                const float *t = tab + (size_t)pos * ld;
+                char best = 0;
+                if (pick) {                                       // idxmin: first minimum wins (SSM.py:32-42)
+                    int bi = -1;
+                    double bv = 0;
+                    for (int a = 0; a < 20; ++a) {
+                        if (!cys && kAA20[a] == 'C') continue;
+                        if (bi < 0 || (double)t[a] < bv) { bi = a; bv = t[a]; }
+                    }
+                    best = kAA20[bi];
+                }
+                for (int a = 0; a < (pick ? 1 : 20); ++a) {
+                    if (!pick && !cys && kAA20[a] == 'C') continue;
+                    o = put_int(o, row++);
+                    memcpy(o, head.data(), head.size()); o += head.size();
+                    o += repr_double((double)t[a], o);
+                    *o++ = ',';
+                    o = put_int(o, pos);
+                    *o++ = ','; *o++ = wt; *o++ = ','; *o++ = kAA20[a]; *o++ = ',';
+                    if (schema == 0) {
+                        if (nb) o = put_int(o, nb[pos]);
+                        *o++ = ',';
+                        if (best) *o++ = best;
+                        *o++ = ',';
+                        memcpy(o, f_name.data(), f_name.size()); o += f_name.size();
+                    } else {
+                        memcpy(o, f_name.data(), f_name.size()); o += f_name.size();
+                        *o++ = ',';
+                        memcpy(o, f_chain.data(), f_chain.size()); o += f_chain.size();
+                    }
+                    *o++ = '\n';
+                }
+            }
+            const size_t len = (size_t)(o - buf.data());
+            int64_t at;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return commit == i; });
+                at = off;
+                off += (int64_t)len;
+                ++commit;
+            }
+            cv.notify_all();
+            if (len && !write_all_at(c->fd, buf.data(), len, at)) failed = true;
+        }
+    };
+    n_threads = std::max(1, std::min(n_threads, std::max(n, 1)));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (failed) return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: write to %s failed: %s", c->path.c_str(), strerror(errno));
+    c->rows = first[n];
+    c->bytes = off;
+    return TMPNN_OK;
+}
+
+// An explicit mutation list (BASELINE config 4; ssm_scan --mutations): triples [m, 3] int64 HOST of (protein, 0-based
+// position, amino-acid index < 20), rows in list order, schema 0 cells, best_AA empty.
+extern "C" int tmpnn_csv_write_listed(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
+                                      const char *const *seqs, const char *const *names, const int32_t *neighbors,
+                                      const char *model, const char *dataset, const int64_t *triples, int64_t m) {
+    if (!c || c->schema != 0 || !offsets || n < 0 || ld < 20 || m < 0 || (m > 0 && (!table || !seqs || !names || !triples)))
+        return tm_set_error(TMPNN_E_INVALID, "csv_write_listed: bad argument");
+    const std::string mid = std::string(",") + csv_field(model) + "," + csv_field(dataset) + ",";
+    std::vector<char> buf;
+    buf.reserve(1 << 20);
+    std::vector<std::string> f_seq((size_t)n), f_name((size_t)n);
+    std::vector<char> have((size_t)n, 0);
+    int64_t at = c->bytes, row = c->rows;
+    auto flush = [&]() -> bool {
+        if (buf.empty()) return true;
+        const bool ok = write_all_at(c->fd, buf.data(), buf.size(), at);
+        at += (int64_t)buf.size();
+        buf.clear();
+        return ok;
+    };
+    for (int64_t k = 0; k < m; ++k) {
+        const int64_t i = triples[3 * k], pos = triples[3 * k + 1], a = triples[3 * k + 2];
+        if (i < 0 || i >= n || a < 0 || a >= 20 || pos < 0 || pos >= offsets[i + 1] - offsets[i])
+            return tm_set_error(TMPNN_E_INVALID, "csv_write_listed: triple %lld out of range", (long long)k);
+        if (!have[i]) { f_seq[i] = csv_field(seqs[i]); f_name[i] = csv_field(names[i]); have[i] = 1; }
+        char cell[96];
+        char *o = put_int(cell, row++);
+        buf.insert(buf.end(), cell, o);
+        buf.push_back(',');
+        buf.insert(buf.end(), f_seq[i].begin(), f_seq[i].end());
+        buf.insert(buf.end(), mid.begin(), mid.end());
+        const size_t r = (size_t)(offsets[i] + pos);
+        o = cell;
+        o += repr_double((double)table[r * ld + a], o);
+        *o++ = ',';
+        o = put_int(o, pos);
+        *o++ = ','; *o++ = seqs[i][pos]; *o++ = ','; *o++ = kAA20[a]; *o++ = ',';
+        if (neighbors) o = put_int(o, neighbors[r]);
+        *o++ = ','; *o++ = ',';
+        buf.insert(buf.end(), cell, o);
+        buf.insert(buf.end(), f_name[i].begin(), f_name[i].end());
+        buf.push_back('\n');
+        if (buf.size() > (1 << 20) - 4096 && !flush())
+            return tm_set_error(TMPNN_E_INVALID, "csv_write_listed: write to %s failed: %s", c->path.c_str(), strerror(errno));
+    }
+    if (!flush()) return tm_set_error(TMPNN_E_INVALID, "csv_write_listed: write to %s failed: %s", c->path.c_str(), strerror(errno));
+    c->rows = row;
+    c->bytes = at;
+    return TMPNN_OK;
+}
+
+// repr(float(x)) as a C string (what the writer puts in the ddG_pred cell); exported so the host tests can pin the number
+// format against Python's own repr on arbitrary values. buf must hold 32 bytes. -> length.
+extern "C" int tmpnn_csv_format_double(double v, char *buf) {
+    if (!buf) return tm_set_error(TMPNN_E_INVALID, "csv_format_double: null buffer");
+    const int n = repr_double(v, buf);
+    buf[n] = '\0';
+    return n;
+}

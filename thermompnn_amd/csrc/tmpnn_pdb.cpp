@@ -9,16 +9,20 @@
 //   - unknown residue names -> '-'  (:262-266);  packing: '-' -> 'X' (20), mask = all 12 backbone coords finite,
 //     NaN -> 0, residue_idx = 100 (c-1) + position, chain_encoding = c (1-based), chains in the requested order
 #include <ctype.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
-#include <map>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 // Host-only translation unit: it needs the C-ABI header and the library's error sink, nothing of HIP — so the same file
@@ -35,53 +39,79 @@ namespace {
 constexpr long kMaxChainSpan = 200000;
 
 struct Residue {
-    std::string name;           // first residue name seen
-    bool have[4] = {false, false, false, false};
+    long num = 0;               // residue number - 1
+    char ins = 0;               // insertion code, 0 = none (sorts first, like the reference's "" sub-key)
+    char name[3] = {0, 0, 0};   // first residue name seen
+    unsigned have = 0;          // bit a = backbone atom a seen (first occurrence wins)
     double xyz[4][3];
 };
 struct ChainAcc {
-    std::map<long, std::map<std::string, Residue>> res;   // number-1 -> insertion code -> residue
+    std::vector<Residue> res;                       // in order of first appearance; sorted by (num, ins) at the end if needed
+    std::unordered_map<int64_t, int> index;         // (num, ins) -> slot; consulted only when the key changes between records
     long lo = 0, hi = 0;
-    bool any = false;
+    int last = -1;
+    bool any = false, sorted = true;
 };
 
-const char *kAA3[20] = {"ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE",
-                        "LEU", "LYS", "MET", "PHE", "PRO", "SER", "THR", "TRP", "TYR", "VAL"};
+const char kAA3[20][4] = {"ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE",
+                          "LEU", "LYS", "MET", "PHE", "PRO", "SER", "THR", "TRP", "TYR", "VAL"};
 const char kAA1[21] = "ARNDCQEGHILKMFPSTWYV";
 const char kMpnn[22] = "ACDEFGHIKLMNPQRSTVWYX";
 
-char one_letter(const std::string &name) {
+char one_letter(const char name[3]) {
     for (int i = 0; i < 20; ++i)
-        if (name == kAA3[i]) return kAA1[i];
+        if (name[0] == kAA3[i][0] && name[1] == kAA3[i][1] && name[2] == kAA3[i][2]) return kAA1[i];
     return '-';
 }
 
-bool parse_double(const std::string &line, size_t a, size_t b, double *out) {
-    if (line.size() <= a) return false;
-    std::string f = line.substr(a, std::min(b, line.size()) - a);
-    const char *p = f.c_str();
-    while (*p && isspace((unsigned char)*p)) ++p;
-    if (!*p) return false;
-    char *end = nullptr;
-    *out = strtod(p, &end);
-    while (*end && isspace((unsigned char)*end)) ++end;
-    return end != p && *end == '\0';
-}
+inline bool is_space(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
 
-std::string strip(const std::string &s) {
-    size_t a = 0, b = s.size();
-    while (a < b && isspace((unsigned char)s[a])) ++a;
-    while (b > a && isspace((unsigned char)s[b - 1])) --b;
-    return s.substr(a, b - a);
+// float(field) of the reference (:230). Fast path: [spaces][sign]digits[.digits][spaces] with at most 15 digits — the
+// integer mantissa and the power of ten are both exact doubles, so ONE correctly rounded division gives the correctly rounded
+// value, i.e. what strtod / Python return (Clinger's fast path). Everything else (exponents, inf / nan, long fields) goes
+// through strtod on a copy.
+bool parse_double(const char *p, size_t n, size_t a, size_t b, double *out) {
+    if (n <= a) return false;
+    b = std::min(b, n);
+    const char *s = p + a, *e = p + b;
+    while (s < e && is_space(*s)) ++s;
+    while (e > s && is_space(e[-1])) --e;
+    if (s == e) return false;
+    static const double kPow10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+    const char *q = s;
+    bool neg = false;
+    if (*q == '-' || *q == '+') { neg = *q == '-'; ++q; }
+    uint64_t m = 0;
+    int digits = 0, frac = 0;
+    bool dot = false, ok = q < e;
+    for (; q < e; ++q) {
+        const char c = *q;
+        if (c >= '0' && c <= '9') { m = m * 10 + (uint64_t)(c - '0'); ++digits; frac += dot; }
+        else if (c == '.' && !dot) dot = true;
+        else { ok = false; break; }
+    }
+    if (ok && digits >= 1 && digits <= 15) {
+        const double v = (double)m / kPow10[frac];
+        *out = neg ? -v : v;
+        return true;
+    }
+    char buf[64];
+    const size_t len = (size_t)(e - s);
+    if (len >= sizeof(buf)) return false;
+    memcpy(buf, s, len);
+    buf[len] = '\0';
+    if (memchr(buf, '\0', len) != nullptr && strlen(buf) != len) return false;     // an embedded NUL is not a number
+    char *end = nullptr;
+    *out = strtod(buf, &end);
+    return end != buf && *end == '\0';
 }
 
 // bytes.decode("utf-8", "ignore") of the reference (:211), column-exact: a well-formed multi-byte sequence is ONE column
 // (kept as '?': no ATOM field compares equal to a non-ASCII character), ill-formed bytes vanish (maximal-subpart rule, as
 // CPython's decoder applies it), ASCII passes through.
-std::string utf8_ignore(const std::string &in) {
+std::string utf8_ignore(const char *in, size_t n) {
     std::string out;
-    out.reserve(in.size());
-    const size_t n = in.size();
+    out.reserve(n);
     size_t i = 0;
     while (i < n) {
         const unsigned char b = (unsigned char)in[i];
@@ -116,6 +146,89 @@ void replace_all(std::string &s, const char *from, const char *to) {
     for (size_t p = s.find(from); p != std::string::npos; p = s.find(from, p + nt)) s.replace(p, nf, to);
 }
 
+bool read_file(const char *path, std::vector<char> *buf) {
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    size_t cap = (fstat(fd, &st) == 0 && st.st_size > 0) ? (size_t)st.st_size + 1 : 1 << 16, len = 0;
+    buf->resize(cap);
+    for (;;) {
+        if (len == cap) { cap *= 2; buf->resize(cap); }
+        const ssize_t r = read(fd, buf->data() + len, cap - len);
+        if (r < 0) { if (errno == EINTR) continue; close(fd); return false; }
+        if (r == 0) break;
+        len += (size_t)r;
+    }
+    close(fd);
+    buf->resize(len);
+    return true;
+}
+
+enum LineResult { kSkip, kTaken, kBad, kSpan };
+
+// One ATOM record (already decoded, right-stripped, MSE-rewritten): columns as at :222-231.
+inline LineResult take_atom(const char *p, size_t n, const bool *want, bool any_wanted, ChainAcc *acc) {
+    if (n < 22 || p[0] != 'A' || p[1] != 'T' || p[2] != 'O' || p[3] != 'M') return kSkip;
+    const unsigned char ch = (unsigned char)p[21];
+    if (any_wanted && !want[ch]) return kSkip;
+    // residue number + insertion code, columns 22-26 stripped
+    size_t ra = 22, rb = std::min(n, (size_t)27);
+    while (ra < rb && is_space(p[ra])) ++ra;
+    while (rb > ra && is_space(p[rb - 1])) --rb;
+    double xyz[3];
+    if (ra == rb || !parse_double(p, n, 30, 38, &xyz[0]) || !parse_double(p, n, 38, 46, &xyz[1]) ||
+        !parse_double(p, n, 46, 54, &xyz[2])) return kBad;
+    char ins = 0;
+    if (isalpha((unsigned char)p[rb - 1])) { ins = p[rb - 1]; --rb; }
+    size_t q = ra;
+    bool neg = false;
+    if (q < rb && (p[q] == '-' || p[q] == '+')) { neg = p[q] == '-'; ++q; }
+    if (q == rb) return kBad;
+    long num = 0;
+    for (; q < rb; ++q) {
+        if (p[q] < '0' || p[q] > '9') return kBad;
+        num = num * 10 + (p[q] - '0');
+    }
+    num = (neg ? -num : num) - 1;
+    ChainAcc &c = acc[ch];
+    if (!c.any) { c.lo = c.hi = num; c.any = true; }
+    c.lo = std::min(c.lo, num);
+    c.hi = std::max(c.hi, num);
+    if (c.hi - c.lo >= kMaxChainSpan) return kSpan;
+    Residue *r;
+    if (c.last >= 0 && c.res[c.last].num == num && c.res[c.last].ins == ins) {
+        r = &c.res[c.last];
+    } else {
+        const int64_t key = (int64_t)num * 256 + (unsigned char)ins;
+        auto it = c.index.find(key);
+        if (it == c.index.end()) {
+            if (!c.res.empty()) {
+                const Residue &b = c.res.back();
+                if (num < b.num || (num == b.num && (unsigned char)ins < (unsigned char)b.ins)) c.sorted = false;
+            }
+            c.index.emplace(key, (int)c.res.size());
+            c.last = (int)c.res.size();
+            c.res.emplace_back();
+            r = &c.res.back();
+            r->num = num;
+            r->ins = ins;
+            memcpy(r->name, p + 17, 3);                       // n >= 22: the three name columns exist
+        } else {
+            c.last = it->second;
+            r = &c.res[c.last];
+        }
+    }
+    // atom name, columns 12-15 stripped
+    size_t aa = 12, ab = 16;
+    while (aa < ab && is_space(p[aa])) ++aa;
+    while (ab > aa && is_space(p[ab - 1])) --ab;
+    int ai = -1;
+    if (ab - aa == 1) ai = p[aa] == 'N' ? 0 : p[aa] == 'C' ? 2 : p[aa] == 'O' ? 3 : -1;
+    else if (ab - aa == 2 && p[aa] == 'C' && p[aa + 1] == 'A') ai = 1;
+    if (ai >= 0 && !(r->have & (1u << ai))) { r->have |= 1u << ai; memcpy(r->xyz[ai], xyz, sizeof(xyz)); }
+    return kTaken;
+}
+
 }  // namespace
 
 struct tmpnn_pdb {
@@ -127,94 +240,93 @@ struct tmpnn_pdb {
 };
 
 static int parse_one(const char *path, const char *chains, tmpnn_pdb **out, std::string *err) {
-    FILE *fh = fopen(path, "rb");
-    if (!fh) { *err = std::string("cannot open ") + path; return TMPNN_E_INVALID; }
-    std::string want = chains ? chains : "";
-    std::map<char, ChainAcc> acc;
-    std::vector<char> first_seen;    // default order = the reference's A-Z, a-z scan; here: requested or alphabet order
-    std::string line;
-    char buf[512];
+    std::vector<char> file;
+    if (!read_file(path, &file)) { *err = std::string("cannot open ") + path; return TMPNN_E_INVALID; }
+    const std::string want_s = chains ? chains : "";
+    bool want[256] = {false};
+    for (unsigned char c : want_s) want[c] = true;
+    std::vector<ChainAcc> acc(256);
+    std::string scratch;
     bool bad = false, span = false;
-    while (fgets(buf, sizeof(buf), fh)) {
-        line.assign(buf);
-        while (!line.empty() && strchr("\r\n", line.back()) == nullptr && !feof(fh) && line.size() % (sizeof(buf) - 1) == 0) {
-            if (!fgets(buf, sizeof(buf), fh)) break;     // very long line: keep reading
-            line += buf;
+    const char *p = file.data(), *end = p + file.size();
+    while (p < end && !bad && !span) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *lp = p;
+        size_t n = (size_t)(le - lp);
+        p = nl ? nl + 1 : end;
+        bool ascii = true;
+        for (size_t i = 0; i < n; ++i) if ((unsigned char)lp[i] >= 0x80) { ascii = false; break; }
+        if (!ascii) {                                          // rare: decode, then look at the decoded columns
+            scratch = utf8_ignore(lp, n);
+            lp = scratch.data();
+            n = scratch.size();
         }
-        line = utf8_ignore(line);
-        while (!line.empty() && isspace((unsigned char)line.back())) line.pop_back();
-        if (line.compare(0, 6, "HETATM") == 0 && line.size() >= 20 && line.compare(17, 3, "MSE") == 0) {
-            replace_all(line, "HETATM", "ATOM  ");
-            replace_all(line, "MSE", "MET");
+        while (n > 0 && is_space(lp[n - 1])) --n;
+        if (n >= 20 && memcmp(lp, "HETATM", 6) == 0 && memcmp(lp + 17, "MSE", 3) == 0) {
+            std::string t(lp, n);                              // (scratch may alias lp)
+            replace_all(t, "HETATM", "ATOM  ");
+            replace_all(t, "MSE", "MET");
+            scratch.swap(t);
+            lp = scratch.data();
+            n = scratch.size();
         }
-        if (line.compare(0, 4, "ATOM") != 0 || line.size() < 22) continue;
-        const char ch = line[21];
-        if (!want.empty() && want.find(ch) == std::string::npos) continue;
-        const std::string atom = strip(line.substr(12, 4));
-        const std::string resname = line.size() >= 20 ? line.substr(17, 3) : line.substr(17);
-        std::string resn = strip(line.size() >= 27 ? line.substr(22, 5) : line.substr(22));
-        double xyz[3];
-        if (resn.empty() || !parse_double(line, 30, 38, &xyz[0]) || !parse_double(line, 38, 46, &xyz[1]) ||
-            !parse_double(line, 46, 54, &xyz[2])) { bad = true; break; }
-        std::string ins;
-        if (isalpha((unsigned char)resn.back())) { ins = resn.substr(resn.size() - 1); resn.pop_back(); }
-        char *end = nullptr;
-        const long num = strtol(resn.c_str(), &end, 10) - 1;
-        if (end == resn.c_str() || *end != '\0') { bad = true; break; }
-        ChainAcc &c = acc[ch];
-        if (!c.any) { c.lo = c.hi = num; c.any = true; }
-        c.lo = std::min(c.lo, num);
-        c.hi = std::max(c.hi, num);
-        if (c.hi - c.lo >= kMaxChainSpan) { span = true; break; }
-        Residue &r = c.res[num][ins];
-        if (r.name.empty()) r.name = resname;
-        int ai = atom == "N" ? 0 : atom == "CA" ? 1 : atom == "C" ? 2 : atom == "O" ? 3 : -1;
-        if (ai >= 0 && !r.have[ai]) { r.have[ai] = true; memcpy(r.xyz[ai], xyz, sizeof(xyz)); }
+        const LineResult r = take_atom(lp, n, want, !want_s.empty(), acc.data());
+        bad = r == kBad;
+        span = r == kSpan;
     }
-    fclose(fh);
     if (span) { *err = std::string("residue numbers of one chain span more than 200000 in ") + path; return TMPNN_E_INVALID; }
     if (bad) { *err = std::string("malformed ATOM record in ") + path; return TMPNN_E_INVALID; }
 
-    std::string order = want;
+    std::string order = want_s;
     if (order.empty()) {             // the reference's default chain alphabet: A-Z, a-z, then digits as found
         for (char c = 'A'; c <= 'Z'; ++c) order.push_back(c);
         for (char c = 'a'; c <= 'z'; ++c) order.push_back(c);
         for (char c = '0'; c <= '9'; ++c) order.push_back(c);
     }
-    tmpnn_pdb *p = new tmpnn_pdb();
+    tmpnn_pdb *pd = new tmpnn_pdb();
+    size_t rows = 0;
+    for (unsigned char ch : order)
+        if (acc[ch].any) rows += std::max<size_t>(acc[ch].res.size(), (size_t)(acc[ch].hi - acc[ch].lo + 1));
+    pd->X.reserve(rows * 12); pd->S.reserve(rows); pd->ridx.reserve(rows); pd->cenc.reserve(rows); pd->mask.reserve(rows);
+    pd->seq.reserve(rows);
     int cnum = 1;
     long pos = 0;
     const float nanf_ = nanf("");
-    for (char ch : order) {
-        auto it = acc.find(ch);
-        if (it == acc.end()) continue;
-        const ChainAcc &c = it->second;
+    for (unsigned char ch : order) {
+        ChainAcc &c = acc[ch];
+        if (!c.any) continue;
+        if (!c.sorted)
+            std::stable_sort(c.res.begin(), c.res.end(), [](const Residue &a, const Residue &b) {
+                return a.num != b.num ? a.num < b.num : (unsigned char)a.ins < (unsigned char)b.ins; });
+        auto emit = [&](const Residue *r) {
+            const char aa = r ? one_letter(r->name) : '-';
+            pd->seq.push_back(aa);
+            const char m = aa == '-' ? 'X' : aa;
+            pd->S.push_back((int32_t)(strchr(kMpnn, m) - kMpnn));
+            bool finite = true;
+            for (int a = 0; a < 4; ++a)
+                for (int k = 0; k < 3; ++k) {
+                    const bool ok = r && (r->have & (1u << a));
+                    pd->X.push_back(ok ? (float)r->xyz[a][k] : nanf_);
+                    finite = finite && ok && std::isfinite(r->xyz[a][k]);
+                }
+            pd->mask.push_back(finite ? 1.f : 0.f);
+            pd->ridx.push_back((int32_t)(100 * (cnum - 1) + pos));
+            pd->cenc.push_back(cnum);
+            ++pos;
+        };
+        size_t k = 0;
         for (long num = c.lo; num <= c.hi; ++num) {
-            auto rit = c.res.find(num);
-            auto emit = [&](const Residue *r) {
-                const char aa = r ? one_letter(r->name) : '-';
-                p->seq.push_back(aa);
-                const char m = aa == '-' ? 'X' : aa;
-                p->S.push_back((int32_t)(strchr(kMpnn, m) - kMpnn));
-                bool finite = true;
-                for (int a = 0; a < 4; ++a)
-                    for (int k = 0; k < 3; ++k) {
-                        const bool ok = r && r->have[a];
-                        p->X.push_back(ok ? (float)r->xyz[a][k] : nanf_);
-                        finite = finite && ok && std::isfinite(r->xyz[a][k]);
-                    }
-                p->mask.push_back(finite ? 1.f : 0.f);
-                p->ridx.push_back((int32_t)(100 * (cnum - 1) + pos));
-                p->cenc.push_back(cnum);
-                ++pos;
-            };
-            if (rit == c.res.end()) emit(nullptr);
-            else for (const auto &kv : rit->second) emit(&kv.second);   // std::map iterates insertion codes sorted, "" first
+            if (k < c.res.size() && c.res[k].num == num)
+                for (; k < c.res.size() && c.res[k].num == num; ++k) emit(&c.res[k]);   // insertion codes sorted, none first
+            else
+                emit(nullptr);
         }
         ++cnum;
-        ++p->n_chains;
+        ++pd->n_chains;
     }
-    *out = p;
+    *out = pd;
     return TMPNN_OK;
 }
 
@@ -278,3 +390,39 @@ extern "C" int tmpnn_pdb_fill(const tmpnn_pdb_t *p, float *X, int32_t *S, float 
 }
 
 extern "C" void tmpnn_pdb_free(tmpnn_pdb_t *p) { delete p; }
+
+extern "C" const char *tmpnn_pdb_seq(const tmpnn_pdb_t *p) { return p ? p->seq.c_str() : nullptr; }
+
+// Many parsed structures -> ONE ragged batch in the caller's (pinned) host buffers, protein after protein: the layout
+// tmpnn_ssm_forward consumes, so a many-PDB scan goes file -> handle -> staging buffer -> one async H2D copy with no
+// per-protein Python object in between.
+extern "C" int tmpnn_pdb_pack_batch(tmpnn_pdb_t *const *handles, int n, int n_threads, int64_t capacity, float *X,
+                                    int32_t *S, float *mask, int32_t *residue_idx, int32_t *chain_enc, float *ca_mask,
+                                    int32_t *offsets) {
+    if (n < 0 || (n > 0 && !handles) || !offsets) return tm_set_error(TMPNN_E_INVALID, "pdb_pack_batch: bad argument");
+    int64_t tot = 0;
+    offsets[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i]) return tm_set_error(TMPNN_E_INVALID, "pdb_pack_batch: handle %d is null", i);
+        tot += (int64_t)handles[i]->S.size();
+        if (tot > INT32_MAX) return tm_set_error(TMPNN_E_INVALID, "pdb_pack_batch: more than 2^31 residues in one batch");
+        offsets[i + 1] = (int32_t)tot;
+    }
+    if (tot > capacity)
+        return tm_set_error(TMPNN_E_WORKSPACE, "pdb_pack_batch: %lld residues, buffers hold %lld", (long long)tot, (long long)capacity);
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            const size_t o = (size_t)offsets[i];
+            tmpnn_pdb_fill(handles[i], X ? X + o * 12 : nullptr, S ? S + o : nullptr, mask ? mask + o : nullptr,
+                           residue_idx ? residue_idx + o : nullptr, chain_enc ? chain_enc + o : nullptr, nullptr,
+                           ca_mask ? ca_mask + o : nullptr);
+        }
+    };
+    n_threads = std::max(1, std::min(n_threads, n));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    return TMPNN_OK;
+}

@@ -83,10 +83,29 @@ def ssm_rows(model, pdb_path: str, chain: str, model_name: str = "ThermoMPNN"):
     return rows
 
 
+def ssm_to_csv(model, pdb_path: str, chain: str, csv_file: str, model_name: str = "ThermoMPNN") -> int:
+    """The script's fast path: native parser -> ONE fused forward -> ONE device-to-host copy of the [L, 21] table -> native
+    columnar writer (csrc/tmpnn_csv.cpp), no Python object per mutation. Same bytes as ``write_csv(ssm_rows(...))``, which
+    goes through the reference-shaped ``TransferModel.forward(pdb, mutations)`` API (tests compare the two files). -> rows."""
+    import numpy as np
+    from . import native_csv, native_pdb
+    p = native_pdb.parse_pdb(pdb_path, chain)
+    L = len(p["seq"])
+    assert L > 0, f"{pdb_path}: chain {chain!r} has no residues"
+    engine = model.engine()
+    with torch.no_grad(), torch.cuda.device(engine.device):
+        out = engine.ssm_forward(p["X"], p["S"], p["mask"], p["residue_idx"], p["chain_enc"], np.array([0, L], np.int32))
+        table = out["ddg"].cpu().numpy()
+    with native_csv.CsvWriter(csv_file, native_csv.SCHEMA_CUSTOM_INFERENCE) as w:
+        w.write_ssm(table, np.array([0, L], np.int32), [p["seq"]], [p["name"].strip(".pdb")], model=model_name,
+                    dataset=pdb_id_of(pdb_path), chain=chain, include_cys=True, n_threads=1)
+    return w.rows
+
+
 def write_csv(rows, path: str) -> None:
     cols = ["Model", "Dataset", "ddG_pred", "position", "wildtype", "mutation", "pdb", "chain"]
     with open(path, "w", newline="") as fh:
-        w = csv.writer(fh)
+        w = csv.writer(fh, lineterminator="\n")           # pandas' to_csv line ends (examples/ThermoMPNN_inference_2OCJ.csv)
         w.writerow([""] + cols)                       # pandas' unnamed index column
         for i, r in enumerate(rows):
             w.writerow([i] + [r[c] for c in cols])
@@ -103,14 +122,19 @@ def main(argv=None):
     ap.add_argument("--allow_pickle", action="store_true", default=False,
                     help="read --model_path with the unrestricted pickle loader (it can execute code from the file); the default "
                          "restricted loader already reads Lightning checkpoints such as thermoMPNN_default.pt")
+    ap.add_argument("--reference_shaped", action="store_true", default=False,
+                    help="go through TransferModel.forward(pdb, mutations) with one Mutation object and one result dict per "
+                         "mutant, as the reference script does (same file, slower host side)")
     args = ap.parse_args(argv)
     chain = args.chain if len(args.chain) >= 1 else first_chain(args.pdb)
     out_dir = os.getcwd() if args.out_dir == "./" else args.out_dir
     assert os.path.isdir(out_dir), f"{out_dir} is not a valid directory."
     model = load_model(args.model_path, args.thermompnn_dir, args.synthetic_weights, allow_pickle=args.allow_pickle or None)
-    rows = ssm_rows(model, args.pdb, chain)
     csv_file = os.path.join(out_dir, "ThermoMPNN_inference_%s.csv" % pdb_id_of(args.pdb))
-    write_csv(rows, csv_file)
+    if args.reference_shaped:
+        write_csv(ssm_rows(model, args.pdb, chain), csv_file)
+    else:
+        ssm_to_csv(model, args.pdb, chain, csv_file)
     print(f"Saved ThermoMPNN output to {csv_file}")
     return csv_file
 

@@ -48,14 +48,36 @@ def all_gather_tables(local: torch.Tensor, rows_per_rank: Sequence[int], group=N
     return [out[r * max_rows: r * max_rows + rows_per_rank[r]] for r in range(world)]
 
 
+def gather_tables_root(local: torch.Tensor, rows_per_rank: Sequence[int], group=None, dst: int = 0) -> Optional[List[torch.Tensor]]:
+    """Ragged [rows_r, C] tables -> rank ``dst`` only: ONE padded ``dist.gather`` (ncclGather-style send/recv on RCCL) — 1/N of
+    the all-gather's traffic, for consumers where a single rank writes the result (the ssm_scan CLI). Returns the list of
+    per-rank tables on ``dst`` and None on the other ranks. ``dst`` is a rank of ``group``."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(rows_per_rank) == world
+    max_rows = max(rows_per_rank) if rows_per_rank else 0
+    C = local.shape[1]
+    on_host = local.is_cuda and dist.get_backend(group) != "nccl"       # gloo group (CPU tests / one-device mode): host buffers
+    padded = local.new_zeros((max_rows, C))
+    padded[: local.shape[0]] = local
+    if on_host:
+        padded = padded.cpu()
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bufs, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+    if rank != dst:
+        return None
+    return [(b.to(local.device) if on_host else b)[: rows_per_rank[r]] for r, b in enumerate(bufs)]
+
+
 def scan_sharded(lengths: Sequence[int], compute_shard: Callable[[List[int]], torch.Tensor], group=None,
-                 k_neighbors: int = 48, gather: bool = True) -> Optional[List[torch.Tensor]]:
+                 k_neighbors: int = 48, gather=True) -> Optional[List[torch.Tensor]]:
     """Run a many-protein scan across the process group.
 
     ``compute_shard(protein_ids) -> [sum(L_i for i in ids), C]`` evaluates this rank's proteins (packed in the
     given order) — on a GPU rank that is ``Engine.ssm_forward`` on the packed shard.
-    Returns one [L_i, C] table per protein in the ORIGINAL order on every rank (or only this rank's
-    tables, as a dict-free list with ``None`` holes, when ``gather=False``)."""
+    ``gather``: True / "all" — one all-gather, every rank returns every protein's [L_i, C] table in the ORIGINAL order;
+    "root" — one gather to rank 0, which returns all tables while the other ranks return only their own (``None`` holes);
+    False — no collective, every rank returns only its own tables (``None`` holes)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     shards = partition_proteins(lengths, world, k_neighbors)
@@ -63,10 +85,13 @@ def scan_sharded(lengths: Sequence[int], compute_shard: Callable[[List[int]], to
     local = compute_shard(mine)
     assert local.shape[0] == sum(lengths[i] for i in mine), "compute_shard returned the wrong number of rows"
     tables: List[Optional[torch.Tensor]] = [None] * len(lengths)
+    rows = [sum(lengths[i] for i in s) for s in shards]
     if world == 1 or not gather:
         per_rank = {rank: local}
+    elif gather == "root":
+        got = gather_tables_root(local, rows, group, 0)
+        per_rank = dict(enumerate(got)) if got is not None else {rank: local}
     else:
-        rows = [sum(lengths[i] for i in s) for s in shards]
         per_rank = dict(enumerate(all_gather_tables(local, rows, group)))
     for r, table in per_rank.items():
         pos = 0
@@ -93,7 +118,7 @@ def pack_proteins(proteins: Sequence[dict], ids: Sequence[int], device):
                 max_len=max(lens))
 
 
-def ssm_scan(engine, proteins: Sequence[Optional[dict]], group=None, gather: bool = True, centrality: bool = False,
+def ssm_scan(engine, proteins: Sequence[Optional[dict]], group=None, gather=True, centrality: bool = False,
              chunk_residues: int = 1 << 18, radius: float = 10.0, lengths: Optional[Sequence[int]] = None):
     """Full SSM of many proteins, sharded over the group's GPUs (analysis/SSM.py:105-126 runs them one per forward).
 
@@ -103,6 +128,8 @@ def ssm_scan(engine, proteins: Sequence[Optional[dict]], group=None, gather: boo
     atom) rides along as a 22nd column, so there is still a single collective.
     ``lengths``: every protein's length when ``proteins`` only holds THIS rank's shard (``None`` elsewhere) — a rank then never
     needs the structures it does not compute (``parse_sharded``: each rank parses ~2/N of the files instead of all).
+    ``gather``: True (all-gather: the API default, every rank gets every table), "root" (one gather to rank 0: what a
+    driver needs when only rank 0 writes), False (no exchange).
     -> list of [L_i, 21] ddG tables (device tensors) in the original order — or (tables, [L_i] int32 counts)."""
     lengths = [len(p["S"]) for p in proteins] if lengths is None else [int(x) for x in lengths]
     assert len(lengths) == len(proteins)
@@ -148,18 +175,130 @@ def parse_sharded(paths: Sequence[str], chains: Optional[Sequence] = None, group
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = list(range(rank, n, world))
-    got = dict(zip(mine, parse([paths[i] for i in mine], [chains[i] for i in mine])))
-    info = {i: (len(p["S"]), p["seq"], p["name"]) for i, p in got.items()}
+    got, info, err = {}, {}, None
+    try:
+        got = dict(zip(mine, parse([paths[i] for i in mine], [chains[i] for i in mine])))
+        info = {i: (len(p["S"]), p["seq"], p["name"]) for i, p in got.items()}
+    except Exception as e:               # noqa: BLE001 - a bad file on ONE rank must fail EVERY rank (the others would wait in
+        err = f"rank {rank}: {e}"        # the collective below, or in the table exchange, until the backend's timeout)
     if world > 1:
         parts = [None] * world
-        dist.all_gather_object(parts, info, group=group)
-        info = {k: v for part in parts for k, v in part.items()}
+        dist.all_gather_object(parts, (err, info), group=group)
+        raise_first_error([p[0] for p in parts])
+        info = {k: v for part in parts for k, v in part[1].items()}
+    elif err:
+        raise RuntimeError(err)
     lengths = [info[i][0] for i in range(n)]
     shard = partition_proteins(lengths, world, k_neighbors)[rank]
     missing = [i for i in shard if i not in got]
-    got.update(zip(missing, parse([paths[i] for i in missing], [chains[i] for i in missing])))
+    err = None
+    try:
+        got.update(zip(missing, parse([paths[i] for i in missing], [chains[i] for i in missing])))
+    except Exception as e:               # noqa: BLE001
+        err = f"rank {rank}: {e}"
+    agree_or_raise(err, group)
     proteins = [got[i] if i in set(shard) else None for i in range(n)]
     return proteins, lengths, [info[i][1] for i in range(n)], [info[i][2] for i in range(n)]
+
+
+def raise_first_error(errors: Sequence[Optional[str]]) -> None:
+    bad = [e for e in errors if e]
+    if bad:
+        raise RuntimeError("sharded scan failed on %d rank(s): %s" % (len(bad), "; ".join(bad)))
+
+
+def agree_or_raise(err: Optional[str], group=None) -> None:
+    """Every rank reports its error (or None); if any rank failed, ALL ranks raise the same RuntimeError — so a failure that
+    only one rank sees never leaves the others blocked in the next collective."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, err, group=group)
+        raise_first_error(parts)
+    elif err:
+        raise RuntimeError(err)
+
+
+def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, group=None, centrality: bool = False,
+               k_neighbors: Optional[int] = None, **pipeline_kw):
+    """PDB files -> ddG tables on rank 0, sharded over the group's GPUs, each rank running the parse || forward || copy-back
+    pipeline (thermompnn_amd.pipeline.scan_files) on its LPT shard and ONE gather to rank 0 at the end.
+
+    Lengths come from a strided pre-pass (rank r parses files r, r + N, ...: a few hundred microseconds per file) whose
+    (length, sequence, name) triples are exchanged with ``all_gather_object``; a file that fails to parse on one rank fails
+    every rank. -> rank 0: dict(table float32 [T, 21] host array in the ORIGINAL file order, offsets int64 [n+1], seqs, names,
+    neighbors int32 [T] or None, stats); other ranks: the same dict with table / neighbors = None."""
+    import numpy as np
+    from . import native_pdb, pipeline
+    n = len(paths)
+    chains = list(chains) if chains is not None else [None] * n
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    K = int(k_neighbors or engine.K)
+    if world == 1:
+        shard = list(range(n))
+        info = None
+    else:
+        mine, err, part = list(range(rank, n, world)), None, {}
+        try:
+            part = {i: (len(p["S"]), p["seq"], p["name"]) for i, p in
+                    zip(mine, native_pdb.parse_pdbs([paths[i] for i in mine], [chains[i] for i in mine]))}
+        except Exception as e:           # noqa: BLE001
+            err = f"rank {rank}: {e}"
+        parts = [None] * world
+        dist.all_gather_object(parts, (err, part), group=group)
+        raise_first_error([p[0] for p in parts])
+        info = {k: v for p in parts for k, v in p[1].items()}
+        shard = partition_proteins([info[i][0] for i in range(n)], world, K)[rank]
+    C_ = 22 if centrality else 21
+    acc, seqs_l, names_l, lens_l = [], [], [], []
+
+    def sink(ch):
+        t = np.empty((ch.T, C_), np.float32)
+        t[:, :21] = ch.table
+        if centrality:
+            t[:, 21] = ch.neighbors
+        acc.append(t)
+        seqs_l.extend(ch.seqs())
+        names_l.extend(ch.names)
+        lens_l.extend(int(x) for x in np.diff(ch.offsets))
+
+    err, stats = None, None
+    try:
+        stats = pipeline.scan_files(engine, [paths[i] for i in shard], [chains[i] for i in shard], sink, centrality=centrality,
+                                    **pipeline_kw)
+    except Exception as e:               # noqa: BLE001
+        err = f"rank {rank}: {type(e).__name__}: {e}"
+    agree_or_raise(err, group)
+    local = np.concatenate(acc) if acc else np.zeros((0, C_), np.float32)
+    if world == 1:
+        lengths, seqs, names, table = lens_l, seqs_l, names_l, local
+    else:
+        lengths = [info[i][0] for i in range(n)]
+        seqs, names = [info[i][1] for i in range(n)], [info[i][2] for i in range(n)]
+        assert lens_l == [lengths[i] for i in shard], "a file changed between the length pre-pass and the scan"
+        shards = partition_proteins(lengths, world, K)
+        rows = [sum(lengths[i] for i in s) for s in shards]
+        backend = dist.get_backend(group)
+        loc_t = torch.from_numpy(local)
+        if backend == "nccl":
+            loc_t = loc_t.to(engine.device)
+        got = gather_tables_root(loc_t, rows, group, 0)
+        table = None
+        if got is not None:                                  # rank 0: per-rank shard tables -> the original file order
+            starts = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+            table = np.empty((int(starts[-1]), C_), np.float32)
+            for r, g in enumerate(got):
+                g = g.cpu().numpy()
+                pos = 0
+                for i in shards[r]:
+                    table[starts[i]:starts[i + 1]] = g[pos:pos + lengths[i]]
+                    pos += lengths[i]
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    out = dict(table=None, neighbors=None, offsets=offsets, seqs=seqs, names=names, stats=stats)
+    if table is not None:
+        out["table"] = np.ascontiguousarray(table[:, :21])
+        out["neighbors"] = np.rint(table[:, 21]).astype(np.int32) if centrality else None
+    return out
 
 
 def select_mutations(tables: Sequence[torch.Tensor], triples) -> torch.Tensor:

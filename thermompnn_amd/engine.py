@@ -154,9 +154,10 @@ class Engine:
         self._raise_status("tmpnn_knn_topk")
         return E_idx, D_nb
 
-    def centrality(self, X, mask, offsets, radius: float = 10.0):
+    def centrality(self, X, mask, offsets, radius: float = 10.0, out: Optional[torch.Tensor] = None):
         X, mask, offsets = self._f32(X), self._f32(mask), self._i32(offsets)
-        out = torch.empty(X.shape[0], dtype=torch.int32, device=self.device)
+        if out is None:
+            out = torch.empty(X.shape[0], dtype=torch.int32, device=self.device)
         check(self.lib.tmpnn_centrality(_ptr(X), _ptr(mask), _ptr(offsets), offsets.numel() - 1, X.shape[0], float(radius),
                                         _ptr(out), _stream()), "tmpnn_centrality")
         return out

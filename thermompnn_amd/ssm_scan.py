@@ -1,14 +1,17 @@
 """Counterpart of /root/reference/analysis/SSM.py: site-saturation scans over MANY proteins.
 
 The reference runs one protein per forward and appends to a pandas frame cell by cell with one device sync per
-mutation (SSM.py:105-147). Here: native threaded PDB parsing -> ONE ragged batch per chunk -> one fused forward ->
-one device-to-host copy -> columnar CSV writer. Post-processing options keep the reference semantics:
+mutation (SSM.py:105-147). Here a three-stage pipeline over chunks of files (thermompnn_amd/pipeline.py): native threaded
+PDB parsing into pinned staging buffers -> one async H2D copy, one fused ragged forward, one async D2H copy -> native
+columnar CSV writer (csrc/tmpnn_csv.cpp; ``--out x.npz`` writes the binary tables instead), with parse(k+1) || forward(k) ||
+write(k-1). ``rows_for_protein`` / ``write_csv`` below are the reference-shaped per-row form the native writer is tested
+against byte for byte. Post-processing options keep the reference semantics:
   --centrality   'neighbors' column = #CA within 10 A (compute_centrality, SSM.py:129-132,144-145)
   --pick_best    keep one row per position carrying best_AA = argmin ddG (retrieve_best_mutants, SSM.py:32-42,153-162)
   --include_cys  otherwise mutations to C are excluded (from the best-pick, or dropped from the listing; :164-166)
 Launched under ``python -m torch.distributed.run --nproc-per-node N -m thermompnn_amd.ssm_scan ...`` the proteins
-are sharded over the N GPUs (dist.ssm_scan: LPT partition, one RCCL all-gather of the tables) and rank 0 writes the
-CSV; a plain ``python -m thermompnn_amd.ssm_scan`` is the same code with a world of one.
+are sharded over the N GPUs (dist.scan_files: LPT partition, the same pipeline per rank, ONE gather of the tables to rank 0,
+which writes); a plain ``python -m thermompnn_amd.ssm_scan`` streams chunk after chunk into the output file.
   --mutations FILE   CSV with columns pdb,position,mutation (0-based position into the parsed sequence): only the listed
                      mutants are written (BASELINE config 4: an explicit list over many proteins)
 """
@@ -102,10 +105,81 @@ def rows_for_protein(p: dict, table: np.ndarray, neighbors, model_name: str, dat
 
 def write_csv(rows, path: str) -> None:
     with open(path, "w", newline="") as fh:
-        w = csv.writer(fh)
+        w = csv.writer(fh, lineterminator="\n")           # pandas' to_csv line ends (examples/ThermoMPNN_inference_2OCJ.csv)
         w.writerow([""] + COLUMNS)
         for i, r in enumerate(rows):
             w.writerow([i] + [r[c] for c in COLUMNS])
+
+
+def write_scan_csv(path: str, res: dict, model_name: str, dataset: str, pick_best: bool, include_cys: bool,
+                   triples=None, n_threads: int = 0) -> int:
+    """The native columnar writer on a finished scan (``dist.scan_files`` result on rank 0) -> number of rows.
+    Byte-identical to ``write_csv(rows_for_protein(...))`` (tests/test_host.py compares them)."""
+    from . import native_csv
+    names = [n.strip(".pdb") for n in res["names"]]               # SSM.py:139 (a character-set strip)
+    with native_csv.CsvWriter(path, native_csv.SCHEMA_SSM) as w:
+        if triples is not None:
+            w.write_listed(res["table"], res["offsets"], res["seqs"], names, triples, neighbors=res["neighbors"],
+                           model=model_name, dataset=dataset)
+        else:
+            w.write_ssm(res["table"], res["offsets"], res["seqs"], names, neighbors=res["neighbors"], model=model_name,
+                        dataset=dataset, pick_best=pick_best, include_cys=include_cys, n_threads=n_threads)
+    return w.rows
+
+
+def write_scan_npz(path: str, res: dict) -> None:
+    """Binary result: ddg float32 [T, 21] (column a = mutation to ALPHABET[a], column 20 = 'X'), offsets int64 [n+1] (rows of
+    protein i = offsets[i]:offsets[i+1]), names, seqs ('-' = no residue: that row is not a prediction), neighbors (optional).
+    No text formatting at all: the format for downstream code that wants the table, not a spreadsheet."""
+    extra = {} if res.get("neighbors") is None else {"neighbors": res["neighbors"]}
+    with open(path, "wb") as fh:                                  # (np.savez would append ".npz" to a bare name)
+        np.savez(fh, ddg=res["table"], offsets=np.asarray(res["offsets"], dtype=np.int64), names=np.array(res["names"]),
+                 seqs=np.array(res["seqs"]), **extra)
+
+
+def scan_to_file(engine, paths: Sequence[str], chains: Sequence, out: str, model_name: str = "ThermoMPNN",
+                 dataset: str = "custom", pick_best: bool = False, include_cys: bool = False, centrality: bool = False,
+                 n_threads: int = 0, **pipeline_kw):
+    """Single-GPU streaming form: PDB files -> ``out`` (``.npz``: binary tables; anything else: the reference's CSV layout)
+    with parse(k+1) || forward(k) || write(k-1) — a chunk's rows are formatted and written while the GPU works on the next
+    chunk, and nothing but the current chunks is held in memory. -> (rows or residues written, pipeline.ScanStats)."""
+    from . import native_csv, pipeline
+    if out.endswith(".npz"):
+        acc = dict(t=[], nb=[], lens=[], seqs=[], names=[])
+
+        def sink(ch):
+            acc["t"].append(ch.table.copy())
+            if ch.neighbors is not None:
+                acc["nb"].append(ch.neighbors.copy())
+            acc["lens"].extend(int(x) for x in np.diff(ch.offsets))
+            acc["seqs"].extend(ch.seqs())
+            acc["names"].extend(ch.names)
+
+        stats = pipeline.scan_files(engine, paths, chains, sink, centrality=centrality, **pipeline_kw)
+        t0 = _now()
+        res = dict(table=np.concatenate(acc["t"]) if acc["t"] else np.zeros((0, 21), np.float32),
+                   neighbors=np.concatenate(acc["nb"]) if acc["nb"] else None,
+                   offsets=np.concatenate([[0], np.cumsum(acc["lens"])]), seqs=acc["seqs"], names=acc["names"])
+        write_scan_npz(out, res)
+        stats.sink_s += _now() - t0
+        stats.wall_s += _now() - t0
+        return int(res["table"].shape[0]), stats
+    w = native_csv.CsvWriter(out, native_csv.SCHEMA_SSM)
+    nt = n_threads or max(1, pipeline.usable_cpus() - 1)
+    try:
+        def sink(ch):
+            w.write_ssm(ch.table, ch.offsets, ch.seq_ptrs, [n.strip(".pdb") for n in ch.names], neighbors=ch.neighbors,
+                        model=model_name, dataset=dataset, pick_best=pick_best, include_cys=include_cys, n_threads=nt)
+
+        stats = pipeline.scan_files(engine, paths, chains, sink, centrality=centrality, **pipeline_kw)
+    finally:
+        w.close()
+    return w.rows, stats
+
+
+def _now() -> float:
+    import time
+    return time.perf_counter()
 
 
 def main(argv=None):
@@ -116,12 +190,14 @@ def main(argv=None):
     ap.add_argument("--thermompnn_dir", default=".")
     ap.add_argument("--synthetic_weights", type=int, default=None)
     ap.add_argument("--dataset_name", default="custom")
-    ap.add_argument("--out", default="ThermoMPNN_custom_SSM_preds.csv")
+    ap.add_argument("--out", default="ThermoMPNN_custom_SSM_preds.csv",
+                    help="output file; a name ending in .npz gets the binary tables (ddg [T,21], offsets, names, seqs) instead of CSV")
     ap.add_argument("--pick_best", action="store_true", default=False, help="Keep only the BEST mutation at each position")
     ap.add_argument("--include_cys", action="store_true", default=False, help="Include cysteine as potential mutation option.")
     ap.add_argument("--centrality", action="store_true", default=False, help="Calculate centrality value for each residue (# neighbors).")
     ap.add_argument("--mutations", default="", help="CSV (pdb,position,mutation): write only these mutants")
     ap.add_argument("--precision", default=None, choices=["f16x2", "bf16x3", "fp32"])
+    ap.add_argument("--chunk_files", type=int, default=96, help="files per pipeline chunk (parse || forward || write overlap)")
     ap.add_argument("--allow_pickle", action="store_true", default=False,
                     help="read --model_path with the unrestricted pickle loader (it can execute code from the file); the default "
                          "restricted loader already reads Lightning checkpoints such as thermoMPNN_default.pt")
@@ -133,27 +209,32 @@ def main(argv=None):
     model = load_model(args.model_path, args.thermompnn_dir, args.synthetic_weights, device=device, precision=args.precision,
                        allow_pickle=args.allow_pickle or None)
     engine = model.engine()
-    # every rank parses ~2/N of the files (a strided length pre-pass + the rest of its own LPT shard), not all of them
-    shard, lengths, seqs, names = tdist.parse_sharded(args.pdbs, [args.chain] * len(args.pdbs), k_neighbors=engine.K)
+    chains = [args.chain] * len(args.pdbs)
     with torch.cuda.device(engine.device):
-        tables, neigh = scan_proteins(engine, shard, centrality=args.centrality, lengths=lengths)
-    proteins = [{"seq": s_, "name": n_} for s_, n_ in zip(seqs, names)]     # what the writer needs of every protein
-    if rank == 0:
-        rows = []
-        if args.mutations:
-            tri = read_mutation_list(args.mutations, proteins)
-            for i, pos, a in tri:
-                p = proteins[i]
-                rows.append({"WT Seq": p["seq"], "Model": "ThermoMPNN", "Dataset": args.dataset_name,
-                             "ddG_pred": float(tables[i][pos, a]), "position": int(pos), "wildtype": p["seq"][pos],
-                             "mutation": AA20[a], "neighbors": int(neigh[i][pos]) if neigh else "", "best_AA": "",
-                             "pdb": p["name"].strip(".pdb")})
+        if world == 1 and not args.mutations:
+            # one GPU: stream chunks straight into the output while the next ones are parsed and computed
+            n_rows, stats = scan_to_file(engine, args.pdbs, chains, args.out, "ThermoMPNN", args.dataset_name, args.pick_best,
+                                         args.include_cys, args.centrality, chunk_files=args.chunk_files)
+            n_prot = stats.files
         else:
-            for i, p in enumerate(proteins):
-                rows += rows_for_protein(p, tables[i], neigh[i] if neigh else None, "ThermoMPNN", args.dataset_name,
-                                         args.pick_best, args.include_cys)
-        write_csv(rows, args.out)
-        print(f"Saved {len(rows)} rows for {len(proteins)} proteins to {args.out} ({world} rank(s))")
+            # N GPUs: every rank runs the pipeline on its LPT shard, ONE gather to rank 0, which writes
+            res = tdist.scan_files(engine, args.pdbs, chains, centrality=args.centrality, chunk_files=args.chunk_files)
+            n_prot, n_rows = len(res["names"]), 0
+            err = None
+            if rank == 0:
+                try:
+                    if args.out.endswith(".npz"):
+                        write_scan_npz(args.out, res)
+                        n_rows = int(res["table"].shape[0])
+                    else:
+                        tri = read_mutation_list(args.mutations, [{"seq": s_, "name": n_} for s_, n_ in zip(res["seqs"], res["names"])]) \
+                            if args.mutations else None
+                        n_rows = write_scan_csv(args.out, res, "ThermoMPNN", args.dataset_name, args.pick_best, args.include_cys, tri)
+                except Exception as e:       # noqa: BLE001 - the other ranks must not wait at the barrier for a writer that died
+                    err = f"rank 0: {type(e).__name__}: {e}"
+            tdist.agree_or_raise(err)
+    if rank == 0:
+        print(f"Saved {n_rows} rows for {n_prot} proteins to {args.out} ({world} rank(s))")
     if world > 1:
         import torch.distributed as td
         td.barrier()

@@ -37,3 +37,23 @@ def synthetic_pdb_dict(L: int, seed: int = 0, name: str | None = None, chain: st
     return {"resn_list": [str(i + 1) for i in range(L)], f"seq_chain_{chain}": seq,
             f"coords_chain_{chain}": coords, "name": name or f"syn_L{L}_s{seed}",
             "num_of_chains": 1, "seq": seq}
+
+
+AA3 = {"A": "ALA", "R": "ARG", "N": "ASN", "D": "ASP", "C": "CYS", "Q": "GLN", "E": "GLU", "G": "GLY", "H": "HIS", "I": "ILE",
+       "L": "LEU", "K": "LYS", "M": "MET", "F": "PHE", "P": "PRO", "S": "SER", "T": "THR", "W": "TRP", "Y": "TYR", "V": "VAL"}
+
+
+def backbone_pdb_text(X, seq: str, chain: str = "A") -> str:
+    """Backbone-only PDB text (N, CA, C, O records in the fixed columns alt_parse_PDB reads, protein_mpnn_utils.py:222-231)
+    of a synthetic protein: the input files of the end-to-end (PDB -> CSV) measurement."""
+    names = ((" N  ", "N"), (" CA ", "C"), (" C  ", "C"), (" O  ", "O"))
+    out, serial = [], 1
+    Xr = np.asarray(X, dtype=np.float64)
+    for i, aa in enumerate(seq):
+        res = AA3[aa]
+        for a, (nm, el) in enumerate(names):
+            x, y, z = Xr[i, a]
+            out.append(f"ATOM  {serial:5d} {nm} {res} {chain}{i + 1:4d}    {x:8.3f}{y:8.3f}{z:8.3f}  1.00  0.00           {el}")
+            serial += 1
+    out.append("TER\nEND\n")
+    return "\n".join(out)
