@@ -51,8 +51,10 @@ enum {
 enum {
     TMPNN_STATUS_RANGE = 1,    /* a ddG / log-probability is inf or NaN: an activation or weight overflowed the fp16 range of
                                   the "f16x2" matrix-core path (|x| >= 65504) */
-    TMPNN_STATUS_MAXLEN = 2    /* a protein is longer than the max_len the caller passed: its neighbour rows were left
+    TMPNN_STATUS_MAXLEN = 2,   /* a protein is longer than the max_len the caller passed: its neighbour rows were left
                                   empty (E_idx = -1) instead of overrunning the kernel's per-row scratch */
+    TMPNN_STATUS_SELFTEST = 4  /* tmpnn_selftest: the library was built with flags that break its overflow detection or its
+                                  persistent tile loops (-> TMPNN_E_UNSUPPORTED) */
 };
 
 typedef struct tmpnn_weights tmpnn_weights_t;   /* opaque; immutable after create */
@@ -63,6 +65,11 @@ const char *tmpnn_last_error(void);
 /* Maps a status word (host copy) to an error: 0 -> TMPNN_OK; TMPNN_STATUS_MAXLEN -> TMPNN_E_INVALID;
  * TMPNN_STATUS_RANGE -> TMPNN_E_RANGE (message in tmpnn_last_error()). */
 int tmpnn_status_error(int32_t status);
+/* Device self-test of the build (one tiny launch on `stream`, no sync): the f16x2 kernels' GELU must propagate NaN (that is how
+ * an fp16 overflow reaches TMPNN_STATUS_RANGE) and the kernels' view of gridDim / blockDim must match the launch. ORs
+ * TMPNN_STATUS_SELFTEST into the caller-owned device word `status` on failure; hosts run it once per device before trusting a
+ * freshly built library (thermompnn_amd/engine.py does, at the first weight handle). */
+int tmpnn_selftest(int32_t *status, tmpnn_stream_t stream);
 /* "f16x2" (default), "bf16x3" or "fp32": how the per-edge GEMMs (featurizer, message and edge-update kernels) run on
  * the matrix cores. f16x2 = every fp32 operand kept as two fp16 values x = h + l*2^-11 (22 significant bits), three
  * partial products per term on v_mfma_f32_16x16x32_f16 with fp32 accumulation; bf16x3 = exact three-way bf16 split, six

@@ -88,3 +88,18 @@ def test_product_refuses_cpu():
         Engine(synthetic_state_dict(0, "mpnn"), "cpu")
     with pytest.raises(TmpnnError, match="no CPU path"):
         gather_nodes(torch.zeros(1, 4, 8), torch.zeros(1, 4, 2, dtype=torch.long))
+
+
+def test_shipped_library_has_no_environment_switches():
+    """kernel-form switches and phase timers (getenv, hipMalloc + blocking hipMemcpy + fprintf inside
+    launchers) live only in the -DTMPNN_DEBUG_BUILD variant; the shipped library's launchers pick forms from the launch size."""
+    from thermompnn_amd import _lib, build
+    build.build_library()
+    build.build_debug_library()
+    names = [b"TMPNN_KNN_REG", b"TMPNN_KNN_SEL", b"TMPNN_FEAT_IMG", b"TMPNN_FEAT_WAVES", b"TMPNN_FEAT_SPLIT", b"TMPNN_FEAT_PROF",
+             b"TMPNN_HEAD_SPLIT", b"TMPNN_NODE_IMG", b"TMPNN_NODE_SPLIT", b"TMPNN_NODE_DEEP", b"TMPNN_NODE_PROF", b"TMPNN_EDGE_PROF",
+             b"TMPNN_MSG_PROF"]
+    shipped, debug = open(_lib.LIB_PATH, "rb").read(), open(_lib.DEBUG_LIB_PATH, "rb").read()
+    assert not [n for n in names if n in shipped]
+    assert all(n in debug for n in names)
+    assert b"phases (" not in shipped and b"phases (" in debug          # the timers' fprintf formats

@@ -150,3 +150,51 @@ def test_sharded_file_scan_two_ranks_one_device(tmp_path):
     r = _torchrun(["-m", "thermompnn_amd.ssm_scan"] + paths[:3] + [str(bad)] + ["--synthetic_weights", "0", "--out", str(tmp_path / "x.csv")],
                   {"TMPNN_ONE_DEVICE": "1", "PYTHONPATH": repo}, timeout=300)
     assert r.returncode != 0 and "malformed" in (r.stdout + r.stderr)
+
+
+def test_reference_style_driver_runs_unchanged_through_compat(tmp_path):
+    """A driver written the way analysis/custom_inference.py is — the reference's own import lines, get_trained_model,
+    alt_parse_PDB, get_ssm_mutations, Mutation objects, `model(mut_pdb, final_mutation_list)`, `out["ddG"].cpu().item()`
+    (custom_inference.py:11-15,72-97) — with ONLY compat/ on PYTHONPATH, against the golden ddG table."""
+    import subprocess
+    import sys
+    from conftest import load_golden
+    from thermompnn_amd import weights
+    sd = weights.synthetic_state_dict(0)
+    os.makedirs(tmp_path / "vanilla_model_weights")
+    weights.save_vanilla_checkpoint(tmp_path / "vanilla_model_weights" / "v_48_020.pt", weights.split_transfer_state_dict(sd)[0], 48)
+    weights.save_lightning_checkpoint(tmp_path / "thermo.ckpt", sd)
+    code = f"""
+import torch
+from datasets import Mutation
+from train_thermompnn import TransferModelPL
+from protein_mpnn_utils import tied_featurize, alt_parse_PDB
+from thermompnn_benchmarking import get_trained_model
+from SSM import get_ssm_mutations
+import numpy as np
+class AD(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+cfg = AD(model=AD(hidden_dims=[64, 32], subtract_mut=True, num_final_layers=2, freeze_weights=True, load_pretrained=True,
+                  lightattn=True, lr_schedule=True), platform=AD(thermompnn_dir={str(tmp_path)!r}))
+model = get_trained_model(model_name={str(tmp_path / 'thermo.ckpt')!r}, config=cfg, override_custom=True)
+model = model.eval().cuda()
+mut_pdb = alt_parse_PDB({os.path.join(GOLDEN, '2OCJ.pdb')!r}, 'A')
+final = []
+for m in get_ssm_mutations(mut_pdb[0]):
+    if m is None:
+        final.append(None)
+        continue
+    m = m.strip()
+    final.append(Mutation(position=int(m[1:-1]), wildtype=m[0], mutation=m[-1], ddG=None, pdb=mut_pdb[0]['name']))
+with torch.no_grad():
+    pred, _ = model(mut_pdb, final)
+vals = [out["ddG"].cpu().item() for mut, out in zip(final, pred) if mut is not None]
+np.save({str(tmp_path / 'ddg.npy')!r}, np.array(vals, dtype=np.float32))
+"""
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(tmp_path),
+                       env=dict(os.environ, PYTHONPATH=os.path.join(repo, "compat")))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    got = np.load(tmp_path / "ddg.npy").reshape(194, 20)
+    np.testing.assert_allclose(got, load_golden("2OCJ_A")["ddg"][:, :20], atol=1e-4, rtol=0)

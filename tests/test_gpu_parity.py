@@ -611,9 +611,13 @@ def test_precision_default_comes_from_the_environment():
                                  {"TMPNN_NODE_IMG": "0", "TMPNN_FEAT_IMG": "0"}, {"TMPNN_NODE_DEEP": "0", "TMPNN_KNN_REG": "0"}],
                          ids=["fp32_node_featurizer_head", "no_weight_fragment_images", "tall_node_tiles_and_lds_knn_for_small_launches"])
 def test_selectable_kernel_forms_pass_golden_parity(env):
-    """The non-default kernel forms of the f16x2 mode (selected by environment, read once per process) stay parity-green."""
+    """The non-default kernel forms of the f16x2 mode stay parity-green. The switches exist only in the debug variant of the
+    library (libtmpnn_debug.so, -DTMPNN_DEBUG_BUILD; read once per process) — the shipped library ignores them."""
     import subprocess
     import sys
+    from thermompnn_amd import _lib
+    assert os.path.exists(_lib.DEBUG_LIB_PATH), "build the debug variant: python -m thermompnn_amd.build"
+    env = dict(env, TMPNN_LIB=_lib.DEBUG_LIB_PATH)
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import pytest; sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-k', 'fused_forward or ragged_batch', %r]))"
             % (os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0], os.path.dirname(GOLDEN), __file__))

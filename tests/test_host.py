@@ -565,3 +565,55 @@ def test_native_pack_batch_equals_per_file_fill():
     assert [C.string_at(lib.tmpnn_pdb_seq(C.c_void_p(h))).decode() for h in hs] == [s["seq"] for s in single]
     for h in hs:
         lib.tmpnn_pdb_free(C.c_void_p(h))
+
+
+def test_compat_package_resolves_the_reference_import_lines(tmp_path):
+    """compat/ on PYTHONPATH: the import lines of analysis/custom_inference.py:11-15, analysis/SSM.py:10-14 and
+    analysis/thermompnn_benchmarking.py:11-14 resolve VERBATIM to the engine-backed modules, and
+    TransferModelPL.load_from_checkpoint(path, cfg=config).model (thermompnn_benchmarking.py:78-84) loads a Lightning-format
+    checkpoint without Lightning."""
+    import subprocess
+    import sys
+    from thermompnn_amd import weights
+    sd = weights.synthetic_state_dict(0)
+    mp, _ = weights.split_transfer_state_dict(sd)
+    os.makedirs(tmp_path / "vanilla_model_weights")
+    weights.save_vanilla_checkpoint(tmp_path / "vanilla_model_weights" / "v_48_020.pt", mp, 48)
+    weights.save_lightning_checkpoint(tmp_path / "thermo.ckpt", sd)
+    code = f"""
+from datasets import Mutation
+from train_thermompnn import TransferModelPL
+from protein_mpnn_utils import tied_featurize, alt_parse_PDB
+from thermompnn_benchmarking import get_trained_model
+from SSM import get_ssm_mutations
+from datasets import MegaScaleDataset, ddgBenchDataset, FireProtDataset, Mutation
+from protein_mpnn_utils import loss_smoothed, tied_featurize
+from model_utils import featurize
+from thermompnn_benchmarking import compute_centrality, ProteinMPNNBaseline, get_trained_model, ALPHABET
+from transfer_model import get_protein_mpnn
+import datasets, thermompnn_amd, torch
+assert datasets.__file__.endswith('compat/datasets.py') and ALPHABET == 'ACDEFGHIKLMNPQRSTVWYX'
+class AD(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+cfg = AD(model=AD(hidden_dims=[64, 32], subtract_mut=True, num_final_layers=2, freeze_weights=True, load_pretrained=True,
+                  lightattn=True), platform=AD(thermompnn_dir={str(tmp_path)!r}))
+model = TransferModelPL.load_from_checkpoint({str(tmp_path / 'thermo.ckpt')!r}, cfg=cfg).model
+assert isinstance(model, thermompnn_amd.transfer_model.TransferModel)
+want = thermompnn_amd.weights.synthetic_state_dict(0)
+assert all(torch.equal(v, want[k]) for k, v in model.state_dict().items())
+pdb = alt_parse_PDB({PDB!r}, 'A')
+muts = get_ssm_mutations(pdb[0])
+assert len(muts) == 20 * 194 and muts[0] == 'S0A'
+for bad in (MegaScaleDataset, loss_smoothed):
+    try:
+        bad()
+        raise SystemExit('training-side name did not refuse')
+    except NotImplementedError:
+        pass
+print('compat ok')
+"""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(repo, "compat"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0 and "compat ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]

@@ -7,6 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtmpnn.so")
+DEBUG_LIB_PATH = os.path.join(HERE, "libtmpnn_debug.so")     # -DTMPNN_DEBUG_BUILD: kernel-form switches + phase timers (TMPNN_LIB selects it)
 
 OK = 0
 KS = 48
@@ -31,6 +32,7 @@ SIGNATURES = {
     "tmpnn_weights_packed_bytes": (_sz, []),
     "tmpnn_weights_packed_bytes_p": (_sz, [C.c_char_p]),
     "tmpnn_status_error": (_i, [C.c_int32]),
+    "tmpnn_selftest": (_i, [_p, _p]),
     "tmpnn_weights_create": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _p, _sz, _p]),
     "tmpnn_weights_create_p": (_i, [C.POINTER(_p), C.POINTER(_p), _i, _p, _sz, C.c_char_p, _p]),
     "tmpnn_weights_precision": (C.c_char_p, [_p]),
@@ -72,7 +74,7 @@ DEBUG_SIGNATURES = {
     "tmpnn_clock_probe": (_i, [_i, _i, _p, _p, _p]),
 }
 PRECISIONS = ("f16x2", "bf16x3", "fp32")
-STATUS_RANGE, STATUS_MAXLEN = 1, 2
+STATUS_RANGE, STATUS_MAXLEN, STATUS_SELFTEST = 1, 2, 4
 E_RANGE = -5
 
 

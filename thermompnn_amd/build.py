@@ -10,10 +10,17 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtmpnn.so")
+# The debug variant (-DTMPNN_DEBUG_BUILD): the same kernels plus the TMPNN_* kernel-form switches and per-phase timers that the
+# shipped library does not contain (its launchers never read the environment, allocate or synchronise). A/B tests, tools/dbg_*.py
+# and tools/phase_prof.py load it through TMPNN_LIB.
+DEBUG_LIB = os.path.join(HERE, "libtmpnn_debug.so")
 SOURCES = ["tmpnn_api.hip", "tmpnn_graph.hip", "tmpnn_layers.hip", "tmpnn_head.hip", "tmpnn_split.hip", "tmpnn_pdb.cpp", "tmpnn_csv.cpp"]
 HEADERS = ["tmpnn_common.h", "tmpnn_split.h", "tmpnn_internal.h", os.path.join("..", "..", "include", "tmpnn.h"),
            os.path.join("..", "..", "include", "tmpnn_debug.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
+# -mcode-object-version=5: tm_nblk() / tm_bdim() (tmpnn_common.h) read gridDim / blockDim at fixed offsets of the v5
+# implicit-argument block; pinned here and checked on the device by tmpnn_selftest.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
+         "-mcode-object-version=5"]
 # kernels only (.hip): no sNaN-quieting "v_max x, x" in front of every v_min / v_max (the GELU clamps). Device code never
 # relies on NaNs (range checks test the exponent bits); the host-side PDB reader (.cpp) does and keeps IEEE semantics.
 DEVICE_FLAGS = ["-mno-amdgpu-ieee", "-fno-honor-nans"]
@@ -30,10 +37,10 @@ def _hipcc() -> str:
     return exe
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
@@ -70,6 +77,13 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     return out
 
 
+def build_debug_library(force: bool = False, verbose: bool = False) -> str:
+    """libtmpnn_debug.so: every source again with -DTMPNN_DEBUG_BUILD (own object files)."""
+    if not force and not needs_build(DEBUG_LIB):
+        return DEBUG_LIB
+    return build_library(force=True, verbose=verbose, extra_flags=["-DTMPNN_DEBUG_BUILD"], out=DEBUG_LIB, tag=".debug")
+
+
 def build_pdb_sanitizer_driver(out: str | None = None) -> str:
     """The host-side PDB reader (csrc/tmpnn_pdb.cpp, untrusted text in) + tests/native/pdb_fuzz_driver.cpp as ONE executable
     under AddressSanitizer + UndefinedBehaviorSanitizer (g++; a report aborts the process). Used by the malformed-input test."""
@@ -79,7 +93,8 @@ def build_pdb_sanitizer_driver(out: str | None = None) -> str:
     if not gxx:
         raise RuntimeError("g++ not found: the sanitizer driver cannot be built on this machine")
     cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
-           "-Wall", "-pthread", os.path.join(CSRC, "tmpnn_pdb.cpp"), os.path.join(repo, "tests", "native", "pdb_fuzz_driver.cpp"), "-o", out]
+           "-Wall", "-pthread", os.path.join(CSRC, "tmpnn_pdb.cpp"), os.path.join(CSRC, "tmpnn_csv.cpp"),
+           os.path.join(repo, "tests", "native", "pdb_fuzz_driver.cpp"), "-o", out]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("g++ failed on the sanitizer driver:\n" + r.stdout)
@@ -98,3 +113,4 @@ if __name__ == "__main__":
         print(build_library(force=True, verbose=True, extra_flags=flags, out=os.path.join(HERE, f"libtmpnn_{name}.so"), tag="." + name, only=only))
     else:
         print(build_library(force="--force" in sys.argv, verbose=True))
+        print(build_debug_library(force="--force" in sys.argv, verbose=True))

@@ -151,7 +151,17 @@ extern "C" int tmpnn_status_error(int32_t status) {
     if (status & TMPNN_STATUS_RANGE)
         return tm_set_error(TMPNN_E_RANGE, "non-finite ddG / log-probability: an operand left the fp16 range of the f16x2 "
                                            "matrix-core path (|x| >= 65504); use precision \"bf16x3\" (full fp32 range)");
+    if (status & TMPNN_STATUS_SELFTEST)
+        return tm_set_error(TMPNN_E_UNSUPPORTED, "device self-test failed: this libtmpnn.so was built with flags under which the f16x2 "
+                                                 "GELU does not propagate NaN (fp16 overflow would go undetected) or the code-object "
+                                                 "ABI differs from v5 (persistent tile loops would stride wrongly); rebuild with "
+                                                 "python -m thermompnn_amd.build");
     return tm_set_error(TMPNN_E_INVALID, "unknown status bits 0x%x", (unsigned)status);
+}
+
+extern "C" int tmpnn_selftest(int32_t *status, tmpnn_stream_t stream) {
+    if (!status) return tm_set_error(TMPNN_E_INVALID, "selftest: null status word");
+    return launch_selftest(status, (hipStream_t)stream);
 }
 
 extern "C" int tmpnn_version(void) { return TMPNN_VERSION; }

@@ -1001,8 +1001,8 @@ int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N,
     const int64_t blocks = (T + 3) / 4;
     const int64_t cap = (int64_t)tm_num_cus() * 8;
     const int grid = (int)(blocks < cap ? blocks : cap);
-    static const bool reg_rows = [] { const char *e = getenv("TMPNN_KNN_REG"); return !(e && e[0] == '0'); }();
-    static const int sel_rows = [] { const char *e = getenv("TMPNN_KNN_SEL"); return (e && e[0] == '0') ? 0 : 1; }();   // 0: extract-min rounds only (A/B)
+    static const bool reg_rows = TM_DBG_FLAG("TMPNN_KNN_REG", true);
+    static const int sel_rows = TM_DBG_FLAG("TMPNN_KNN_SEL", true) ? 1 : 0;   // 0: extract-min rounds only (A/B, debug build)
     tm_prof_begin("knn", st);
     if (reg_rows && max_len <= 256) knn_kernel<4><<<grid, TM_THREADS, 0, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init, sel_rows);
     else if (reg_rows && max_len <= 512) knn_kernel<8><<<grid, TM_THREADS, 0, st>>>(X, mask, offsets, N, (int)T, max_len, K, E_idx, D_nb, status, init, sel_rows);
@@ -1028,17 +1028,18 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
     for (int b = 0; b < 4; ++b) { a.img_e[b] = img ? tm_find_wimg(w->edge_w + 16 + 128 * b) : nullptr; img = img && a.img_e[b]; }
     a.img_we = img ? tm_find_wimg(w->We_w) : nullptr;
     img = img && a.img_we;
-    static const bool img_off = [] { const char *e = getenv("TMPNN_FEAT_IMG"); return e != nullptr && e[0] == '0'; }();
-    if (img_off) img = false;
+    static const bool img_on = TM_DBG_FLAG("TMPNN_FEAT_IMG", true);
+    if (!img_on) img = false;
     const int64_t cap = tm_num_cus();
-    static const int nw = [] { const char *e = getenv("TMPNN_FEAT_WAVES"); return e ? atoi(e) : 8; }();
+    static const int nw = TM_DBG_INT("TMPNN_FEAT_WAVES", 8);
     // (two split-precision bf16x3 forms of this kernel — half-width tiles, and one 126 KB single-pass plane tile — were
     //  measured and dropped: generating + splitting the 19 200 Gaussians into three planes and the extra LDS traffic cost as
     //  much as the shorter 400->128 GEMM saved: 1.07-1.08 ms vs 1.08 ms)
     tm_prof_begin("featurize", st);
-    static const bool split_ok = [] { const char *e = getenv("TMPNN_FEAT_SPLIT"); return e == nullptr || e[0] != '0'; }();
-    static const bool feat_prof = [] { const char *e = getenv("TMPNN_FEAT_PROF"); return e != nullptr && e[0] == '1'; }();
-    if (tm_matmul_mode() == TM_MM_F16X2 && split_ok && feat_prof) {       // debug: phase timing of workgroup 0 (synchronises!)
+    static const bool split_ok = TM_DBG_FLAG("TMPNN_FEAT_SPLIT", true);
+#ifdef TMPNN_DEBUG_BUILD
+    static const bool feat_prof = TM_DBG_FLAG("TMPNN_FEAT_PROF", false);
+    if (tm_matmul_mode() == TM_MM_F16X2 && split_ok && feat_prof) {       // debug build: phase timing of workgroup 0 (synchronises!)
         static unsigned long long *d_prof = nullptr;
         if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
         (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
@@ -1051,6 +1052,7 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
         tm_prof_end(st);
         return tm_check_launch("edge_featurize");
     }
+#endif
     if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
         if (img) featurize_split_kernel<SplitH2, false, true><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
         else featurize_split_kernel<SplitH2><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);

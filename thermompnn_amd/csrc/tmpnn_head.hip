@@ -413,7 +413,7 @@ int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const 
     const int64_t tiles = (T + best_rows - 1) / best_rows;
     const int grid = (int)(tiles < slots ? tiles : slots);
     tm_prof_begin("head", st);
-    static const bool split_ok = [] { const char *e = getenv("TMPNN_HEAD_SPLIT"); return e == nullptr || e[0] != '0'; }();
+    static const bool split_ok = TM_DBG_FLAG("TMPNN_HEAD_SPLIT", true);
     if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
 #define TM_HEAD8(NRB)                                                             \
     if (a.img[0]) head8_split_kernel<SplitH2, NRB, true><<<grid, 512, 0, st>>>(a); \

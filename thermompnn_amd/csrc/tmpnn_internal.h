@@ -107,8 +107,22 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                      const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt, hipStream_t st);
 int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, hipStream_t st);
+int launch_selftest(int32_t *status, hipStream_t st);
 
 int tm_num_cus();
+// Kernel-form switches (TMPNN_KNN_REG, TMPNN_NODE_DEEP, TMPNN_FEAT_SPLIT ...) and the per-phase timers (TMPNN_*_PROF, which
+// hipMalloc a scratch buffer, copy it back with a blocking hipMemcpy and print) exist ONLY in the debug variant of the library
+//   python -m thermompnn_amd.build --variant debug -DTMPNN_DEBUG_BUILD      (-> libtmpnn_debug.so; select with TMPNN_LIB)
+// The shipped libtmpnn.so picks every kernel form from the launch size and the handle's precision alone: its launchers never
+// read the environment, never allocate device memory and never synchronise (the contract of include/tmpnn.h).
+#ifdef TMPNN_DEBUG_BUILD
+#include <stdlib.h>
+#define TM_DBG_FLAG(name, dflt) ([] { const char *e_ = getenv(name); return e_ ? e_[0] != '0' : (bool)(dflt); }())
+#define TM_DBG_INT(name, dflt) ([] { const char *e_ = getenv(name); return e_ ? atoi(e_) : (int)(dflt); }())
+#else
+#define TM_DBG_FLAG(name, dflt) ((bool)(dflt))
+#define TM_DBG_INT(name, dflt) ((int)(dflt))
+#endif
 // matrix-core path of the per-edge GEMMs (tmpnn_split.h): a property of the weight handle (tmpnn_weights_create_p);
 // TMPNN_PRECISION = f16x2 (default) | bf16x3 | fp32 only picks the default of handles created without one.
 enum { TM_MM_FP32 = 0, TM_MM_BF16X3 = 1, TM_MM_F16X2 = 2 };

@@ -536,8 +536,8 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
             a.img[u] = base[u] ? tm_find_wimg(base[u]) : nullptr;
             if (base[u] && !a.img[u]) all = false;
         }
-        static const bool img_off = [] { const char *e = getenv("TMPNN_NODE_IMG"); return e != nullptr && e[0] == '0'; }();
-        if (!all || img_off) for (int u = 0; u < 13; ++u) a.img[u] = nullptr;
+        static const bool img_on = TM_DBG_FLAG("TMPNN_NODE_IMG", true);
+        if (!all || !img_on) for (int u = 0; u < 13; ++u) a.img[u] = nullptr;
     }
     tm_prof_begin("node_update", st);
     // Tile height (16 / 32 / 48 residues) chosen for load balance: the grid offers 2 workgroup slots per CU, every
@@ -551,7 +551,7 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
         const int64_t cost = rounds * (rows + 16);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rows = rows; }
     }
-    static const bool split_ok = [] { const char *e = getenv("TMPNN_NODE_SPLIT"); return e == nullptr || e[0] != '0'; }();
+    static const bool split_ok = TM_DBG_FLAG("TMPNN_NODE_SPLIT", true);
     if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
         const int rc = launch_node_update_split(a, T, st);
         tm_prof_end(st);

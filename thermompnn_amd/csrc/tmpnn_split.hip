@@ -83,6 +83,29 @@ __global__ __launch_bounds__(512, 2) void gemm_probe_kernel(const float *__restr
     }
 }
 
+// Device self-test of the two things a different compiler / flag set could silently break:
+//  (1) the f16x2 kernels of THIS translation unit detect an fp16 overflow because their GELU propagates NaN — its clamps must
+//      have lowered to gfx950's v_minimum3 / v_maximum3 (build.py FILE_FLAGS: no -fno-honor-nans here). gelu(NaN) must be NaN and
+//      gelu(+inf) non-finite. (gelu(-inf) = -t 2^P(t) + max(-inf, 0) = -4e-8: finite and intended — an overflow reaches GELU as
+//      NaN, never as a lone inf: h = +-inf and l = -+inf meet in one accumulator.)
+//  (2) tm_nblk() / tm_bdim() read gridDim / blockDim from fixed offsets of the code-object-v5 implicit-argument block
+//      (build.py pins -mcode-object-version=5); every persistent tile loop strides by them.
+// Inputs arrive as kernel arguments so nothing folds at compile time. ORs TMPNN_STATUS_SELFTEST into *status on failure.
+__global__ void selftest_kernel(unsigned nan_bits, unsigned inf_bits, int32_t *status) {
+    bool bad = tm_nblk() != (int)gridDim.x || tm_bdim() != (int)blockDim.x;
+    const f2 g = gelu2(f2{__uint_as_float(nan_bits), __uint_as_float(inf_bits)});
+    float gx = g.x, gy = g.y;
+    asm volatile("" : "+v"(gx), "+v"(gy));
+    const unsigned bx = __float_as_uint(gx), by = __float_as_uint(gy);
+    bad = bad || !((bx & 0x7f800000u) == 0x7f800000u && (bx & 0x007fffffu) != 0u);     // NaN in -> NaN out
+    bad = bad || (by & 0x7f800000u) != 0x7f800000u;                                      // +inf in -> non-finite out
+    if (bad && tm_tid() == 0) atomicOr(status, TMPNN_STATUS_SELFTEST);
+}
+int launch_selftest(int32_t *status, hipStream_t st) {
+    selftest_kernel<<<3, 128, 0, st>>>(0x7fc00000u, 0x7f800000u, status);
+    return tm_check_launch("selftest");
+}
+
 int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, hipStream_t st) {
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
@@ -445,8 +468,13 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
     const int grid = (int)(T < cap ? T : cap);
     if (mode == TM_MM_BF16X3) enc_edge8_split_kernel<SplitBF3><<<grid, 512, 0, st>>>(a);
     else {
-        static const bool prof = [] { const char *e = getenv("TMPNN_EDGE_PROF"); return e != nullptr && e[0] == '1'; }();
-        if (prof) {                                  // debug: phase timing of workgroup 0 (synchronises!)
+#ifdef TMPNN_DEBUG_BUILD
+        static const bool prof = TM_DBG_FLAG("TMPNN_EDGE_PROF", false);
+#else
+        constexpr bool prof = false;
+#endif
+        if (prof) {                                  // debug build: phase timing of workgroup 0 (synchronises!)
+#ifdef TMPNN_DEBUG_BUILD
             static unsigned long long *d_prof = nullptr;
             if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
             (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
@@ -455,6 +483,7 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
             (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
             fprintf(stderr, "enc_edge phases (cycles, wg 0): gemm1 %llu gelu+split %llu bar %llu gather+gemm2 %llu gelu+split %llu bar %llu gemm3 %llu resid+stats %llu bar %llu split+ln+store %llu bar %llu\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+#endif
         } else if (T < ((int64_t)1 << 22)) {
             enc_edge8_rp_kernel<SplitH2, false, true><<<grid, 512, 0, st>>>(a);      // projection table < 4 GB: 32-bit gather offsets
         } else {
@@ -792,8 +821,13 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
         if (dec) msg8_split_kernel<SplitBF3, true><<<grid, 512, 0, st>>>(a);
         else msg8_split_kernel<SplitBF3, false><<<grid, 512, 0, st>>>(a);
     } else {
-        static const bool prof = [] { const char *e = getenv("TMPNN_MSG_PROF"); return e != nullptr && e[0] == '1'; }();
-        if (prof && dec) {                           // debug: phase timing of workgroup 0 (synchronises!)
+#ifdef TMPNN_DEBUG_BUILD
+        static const bool prof = TM_DBG_FLAG("TMPNN_MSG_PROF", false);
+#else
+        constexpr bool prof = false;
+#endif
+        if (prof && dec) {                           // debug build: phase timing of workgroup 0 (synchronises!)
+#ifdef TMPNN_DEBUG_BUILD
             static unsigned long long *d_prof = nullptr;
             if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
             (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
@@ -802,6 +836,7 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
             (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
             fprintf(stderr, "dec_msg phases (cycles, wg 0): fetch+gemm1 %llu gelu+split %llu bar %llu split_tile+gather %llu gemm2 %llu gelu+mask %llu bar %llu ksum+store %llu\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+#endif
         } else if (T < ((int64_t)1 << 22)) {           // projection table < 4 GB: 32-bit gather offsets
             if (dec) msg8_rp_kernel<SplitH2, true, false, true><<<grid, 512, 0, st>>>(a);
             else msg8_rp_kernel<SplitH2, false, false, true><<<grid, 512, 0, st>>>(a);
@@ -1298,7 +1333,7 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
     }
     const int64_t tiles = (T + best_rows - 1) / best_rows;
     const int grid = (int)(tiles < slots ? tiles : slots);
-    static const int deep = [] { const char *e = getenv("TMPNN_NODE_DEEP"); return e ? atoi(e) : 1; }();
+    static const int deep = TM_DBG_INT("TMPNN_NODE_DEEP", 1);
     if (deep && a.img[0] && (T + 15) / 16 <= slots) {           // one 16-row tile per workgroup: the deep-prefetch form
         const int g16 = (int)((T + 15) / 16);
         const int np = (a.proj[0].P != nullptr) + (a.proj[1].P != nullptr);
@@ -1309,8 +1344,9 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
             b.img[9] = a.img[11];
             b.img[10] = a.img[12];
         }
-        static const bool prof = [] { const char *e = getenv("TMPNN_NODE_PROF"); return e != nullptr && e[0] == '1'; }();
-        if (prof && np == 2) {                                  // debug: stage stamps of workgroup 0 (synchronises!)
+#ifdef TMPNN_DEBUG_BUILD
+        static const bool prof = TM_DBG_FLAG("TMPNN_NODE_PROF", false);
+        if (prof && np == 2) {                                  // debug build: stage stamps of workgroup 0 (synchronises!)
             static unsigned long long *d_prof = nullptr;
             if (!d_prof) (void)hipMalloc(&d_prof, 32 * sizeof(unsigned long long));
             (void)hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), st);
@@ -1325,13 +1361,15 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
             fprintf(stderr, "\n");
             return tm_check_launch("node_update8_deep");
         }
+#endif
         if (np == 0) node_update8_deep_kernel<0, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
         else if (np == 1) node_update8_deep_kernel<1, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
         else node_update8_deep_kernel<2, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
         return tm_check_launch("node_update8_deep");
     }
-    static const bool prof4 = [] { const char *e = getenv("TMPNN_NODE_PROF"); return e != nullptr && e[0] == '1'; }();
-    if (prof4 && a.img[0] && best_rows == 64) {                 // debug: stage stamps of workgroup 0 (synchronises!)
+#ifdef TMPNN_DEBUG_BUILD
+    static const bool prof4 = TM_DBG_FLAG("TMPNN_NODE_PROF", false);
+    if (prof4 && a.img[0] && best_rows == 64) {                 // debug build: stage stamps of workgroup 0 (synchronises!)
         static unsigned long long *d_prof = nullptr;
         if (!d_prof) (void)hipMalloc(&d_prof, 32 * sizeof(unsigned long long));
         (void)hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), st);
@@ -1343,6 +1381,7 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
         fprintf(stderr, "\n");
         return tm_check_launch("node_update8_split");
     }
+#endif
 #define TM_NODE8(NRB)                                                                    \
     if (a.img[0]) node_update8_split_kernel<SplitH2, NRB, true><<<grid, 512, 0, st>>>(a); \
     else node_update8_split_kernel<SplitH2, NRB, false><<<grid, 512, 0, st>>>(a)

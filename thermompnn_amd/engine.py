@@ -27,6 +27,22 @@ def _need_cuda(*ts):
             raise TmpnnError("the ThermoMPNN HIP engine needs CUDA (ROCm) tensors; there is no CPU path")
 
 
+_selftested: set = set()
+
+
+def _selftest(lib, device) -> None:
+    """tmpnn_selftest once per (library, device) and process: a library built with flags that break the f16x2 overflow
+    detection or the persistent tile loops must not produce numbers. One tiny launch + a 4-byte read-back."""
+    key = (id(lib), device.index)
+    if key in _selftested:
+        return
+    st = torch.zeros(1, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        check(lib.tmpnn_selftest(_ptr(st), _stream()), "tmpnn_selftest")
+    check(lib.tmpnn_status_error(int(st.item())), "tmpnn_selftest")
+    _selftested.add(key)
+
+
 class Weights:
     """Device-resident weight set + the native handle (tmpnn_weights_create)."""
 
@@ -59,6 +75,7 @@ class Weights:
             self.tensors.append(t)
         self.device = device
         self.with_head = with_head
+        _selftest(lib, device)
         nbytes = lib.tmpnn_weights_packed_bytes_p(precision.encode() if precision else None) or lib.tmpnn_weights_packed_bytes()
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)      # (0 = unknown name: create_p reports it)
         arr = (C.c_void_p * n)(*[t.data_ptr() for t in self.tensors])

@@ -1,6 +1,10 @@
-"""debug: register-resident k-NN rows (TMPNN_KNN_REG=1, default) against the LDS form (=0), bit for bit.  python tools/dbg_knn.py (GPU box)"""
+"""debug: the three k-NN row forms, bit for bit — LDS rows (TMPNN_KNN_REG=0), register rows by extract-min rounds
+(TMPNN_KNN_SEL=0) and register rows by threshold + compaction + bitonic sort (the default) — on lattice coordinates with exact
+distance ties, duplicated and masked residues, L < K, L = 64 / 65 / 512 and ragged batches. The switches exist only in the debug
+variant of the library (thermompnn_amd/libtmpnn_debug.so).  python tools/dbg_knn.py (GPU box)"""
 import os, subprocess, sys
 import numpy as np
+DEBUG_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "thermompnn_amd", "libtmpnn_debug.so")
 if len(sys.argv) > 1:
     import torch
     sys.path.insert(0, ".")
@@ -22,12 +26,15 @@ if len(sys.argv) > 1:
         out[f"E{case}"], out[f"D{case}"] = E.cpu().numpy(), D.cpu().numpy()
     np.savez(sys.argv[1], **out)
     sys.exit(0)
-for v in ("0", "1"):
-    subprocess.run([sys.executable, __file__, f"/tmp/knn{v}.npz"], env=dict(os.environ, TMPNN_KNN_REG=v), check=True)
-a, b = np.load("/tmp/knn0.npz"), np.load("/tmp/knn1.npz")
+forms = {"lds": dict(TMPNN_KNN_REG="0"), "reg_min": dict(TMPNN_KNN_REG="1", TMPNN_KNN_SEL="0"), "reg_sel": dict(TMPNN_KNN_REG="1", TMPNN_KNN_SEL="1")}
+for name, env in forms.items():
+    subprocess.run([sys.executable, __file__, f"/tmp/knn_{name}.npz"], env=dict(os.environ, TMPNN_LIB=DEBUG_LIB, **env), check=True)
+ref = np.load("/tmp/knn_lds.npz")
 ok = True
-for k in a.files:
-    same = np.array_equal(a[k].view(np.int32), b[k].view(np.int32))
-    ok &= same
-    print(k, a[k].shape, "identical" if same else f"DIFFERENT at {np.argwhere(a[k].view(np.int32) != b[k].view(np.int32))[:5].tolist()}")
+for name in ("reg_min", "reg_sel"):
+    b = np.load(f"/tmp/knn_{name}.npz")
+    for k in ref.files:
+        same = np.array_equal(ref[k].view(np.int32), b[k].view(np.int32))
+        ok &= same
+        print(name, k, ref[k].shape, "identical" if same else f"DIFFERENT at {np.argwhere(ref[k].view(np.int32) != b[k].view(np.int32))[:5].tolist()}")
 print("ALL IDENTICAL" if ok else "MISMATCH")

@@ -1,4 +1,6 @@
 """TMPNN_NODE_PROF=1 python tools/node_prof.py  (GPU box): stage stamps of node_update8_deep_kernel on one L=256 protein"""
+import os as _os
+_os.environ.setdefault("TMPNN_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "thermompnn_amd", "libtmpnn_debug.so"))   # TMPNN_*_PROF timers exist only in the debug variant
 import sys
 import torch
 sys.path.insert(0, ".")

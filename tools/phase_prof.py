@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault("TMPNN_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "thermompnn_amd", "libtmpnn_debug.so"))   # TMPNN_*_PROF timers exist only in the debug variant
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
