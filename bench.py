@@ -131,6 +131,85 @@ def pmc_traffic(kernel, T):
     return None
 
 
+# Issue cycles per wavefront instruction on one SIMD (DESIGN.md "What the hardware taught us": MFMA and VALU of the two
+# wavefronts of a SIMD are issued from one port and serialise — hetero_probe / pingpong_probe): a wave64 VALU op 4 cycles
+# (packed fp32 measured 5.3, reported as the `packed_5p3` variant), transcendentals quarter rate, v_mfma_f32_16x16x32_{f16,bf16}
+# 16 (8 passes), v_mfma_f32_16x16x4_f32 32.
+ISSUE_CYCLES = {"valu": 4.0, "valu_packed": 4.0, "valu_trans": 16.0}
+ISA_SYMBOLS = {   # bench kernel name -> the instantiation the bench batch launches (f16x2, images, 32-bit gather offsets)
+    "enc_edge": "enc_edge8_rp_kernelI7SplitH2Lb0ELb1E", "enc_msg": "msg8_rp_kernelI7SplitH2Lb0ELb0ELb1E",
+    "dec_msg": "msg8_rp_kernelI7SplitH2Lb1ELb0ELb1E", "featurize": "featurize_split_kernelI7SplitH2Lb0ELb1E"}
+
+
+def mfma_cycles(op):
+    return 32.0 if op.endswith("_f32") and "x4_" in op else 16.0 if "16x16x32" in op else 32.0 if "32x32" in op else 16.0
+
+
+def isa_counts(kernel):
+    """Static per-trip instruction counts of the kernel's tile loop (tools/isa_counts.py -> profiles/r*_isa_counts.json, stamped
+    with the kernel-source hash like the PMC files: counts of other sources are not quoted)."""
+    import glob
+    sym = ISA_SYMBOLS.get(kernel)
+    if sym is None:
+        return None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_isa_counts.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("source_stamp") != kernel_source_stamp():
+                continue
+            for name, e in d["kernels"].items():
+                if sym in name and "tile_loop" in e:
+                    return dict(e["tile_loop"], file=os.path.basename(f), symbol=name, vgprs=e.get("next_free_vgpr"), lds_bytes=e.get("lds_bytes"))
+        except Exception:
+            continue
+    return None
+
+
+def issue_roof(kernel, tiles, n_cus, clock_ghz, avg_ms, waves_per_simd=2):
+    """The THIRD roof: instruction issue. One tile (= one residue's 48 x 128 edge block) is one trip of the
+    persistent loop in each of the workgroup's 8 wavefronts, 2 per SIMD; a SIMD issues VALU and MFMA instructions of its
+    wavefronts one at a time, so t_issue = tiles per CU x waves per SIMD x sum(count x issue cycles) / measured shader clock.
+    What is NOT in it: barriers, LDS and memory latency, the s_waitcnt / s_nop the loop also contains."""
+    c = isa_counts(kernel)
+    if c is None or not clock_ghz:
+        return None
+    mf = {k[5:]: v for k, v in c.items() if k.startswith("mfma:")}
+    cyc_mfma = sum(mfma_cycles(op) * n for op, n in mf.items())
+    cyc_valu = sum(ISSUE_CYCLES[k] * c.get(k, 0) for k in ISSUE_CYCLES)
+    per_wave = cyc_mfma + cyc_valu
+    tiles_per_cu = -(-tiles // n_cus)
+    t = tiles_per_cu * waves_per_simd * per_wave / (clock_ghz * 1e9)
+    t53 = tiles_per_cu * waves_per_simd * (per_wave + 1.3 * c.get("valu_packed", 0)) / (clock_ghz * 1e9)
+    return {"t_issue_us": t * 1e6, "frac": t / (avg_ms * 1e-3), "frac_packed_5p3": t53 / (avg_ms * 1e-3),
+            "cycles_per_wavefront_tile": per_wave, "mfma_cycles": cyc_mfma, "valu_cycles": cyc_valu,
+            "counts_per_wavefront_tile": {"mfma": sum(mf.values()), "valu": c.get("valu", 0), "valu_packed": c.get("valu_packed", 0),
+                                          "valu_trans": c.get("valu_trans", 0), "salu": c.get("salu", 0), "lds": c.get("lds", 0),
+                                          "vmem": c.get("vmem", 0), "barriers": c.get("barrier", 0), "waitcnt": c.get("waitcnt", 0)},
+            "tiles_per_cu": tiles_per_cu, "waves_per_simd": waves_per_simd, "clock_GHz": clock_ghz,
+            "measured_cycles_per_tile": avg_ms * 1e-3 * clock_ghz * 1e9 / tiles_per_cu,
+            "vgprs": c.get("vgprs"), "lds_bytes": c.get("lds_bytes"), "counts_from": c.get("file"), "symbol": c.get("symbol"),
+            "note": "static counts of the shipped code object's tile loop (tools/isa_counts.py); issue cycles: VALU 4 (packed fp32 "
+                    "measured 5.3 -> frac_packed_5p3), transcendental 16, 16x16x32 16-bit MFMA 16, fp32 16x16x4 MFMA 32; one issue port "
+                    "per SIMD shared by its 2 wavefronts (MFMA and VALU time add, DESIGN.md)"}
+
+
+def shader_clock_ghz(lib, device):
+    """Effective shader clock right after the timed region (tmpnn_clock_probe: cycle counter against the 100 MHz reference
+    under a saturated MFMA stream on all CUs)."""
+    try:
+        blocks, iters = 256, 4000
+        out = torch.zeros(2 * blocks, dtype=torch.int64, device=device)
+        sink = torch.zeros(256, device=device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if lib.tmpnn_clock_probe(blocks, iters, C.c_void_p(out.data_ptr()), C.c_void_p(sink.data_ptr()), st) != 0:
+            return None
+        torch.cuda.synchronize()
+        o = out.cpu().view(-1, 2).double()
+        return float(o[:, 0].mean() / (o[:, 1].mean() / 100e6) / 1e9)
+    except Exception:
+        return None
+
+
 def build_batch(n_proteins, L, seed0, device):
     xs, ss = [], []
     for i in range(n_proteins):
@@ -702,6 +781,8 @@ def main():
     lib.tmpnn_profile_select(None)
     eng.check_last_status()                              # a range / max_len problem in the timed work is an error, not a number
     step_spread = spread(events)
+    clock_ghz = shader_clock_ghz(lib, device) if rank == 0 else None
+    n_cus = torch.cuda.get_device_properties(device).multi_processor_count
 
     if strong:
         units_per_step, unit_name = 200000, "listed mutant ddG predictions"
@@ -765,6 +846,9 @@ def main():
                     v["hbm_GBps"] = by / (v["avg_ms"] * 1e-3) / 1e9
                     rf = kernel_roofs(k, T, edges, v["avg_ms"], mode)
                     v["bound"], v["frac_of_binding_roof"] = rf["bound"], rf["frac"]
+                    ir = issue_roof(k, T, n_cus, clock_ghz, v["avg_ms"]) if mode == "f16x2" and not strong else None
+                    if ir:
+                        v["frac_of_issue_roof"], v["t_issue_us"] = ir["frac"], ir["t_issue_us"]
             dom = dom_name
             rf = kernel_roofs(dom, T, edges, kern[dom]["avg_ms"], mode)
             side = rf["hbm"] if rf["bound"] == "hbm" else rf["mfma"]
@@ -776,6 +860,7 @@ def main():
             result["roofline"] = {
                 "bound": rf["bound"], "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                 "traffic": pmc_traffic(dom, T), "kernel": dom, "avg_launch_ms": kern[dom]["avg_ms"],
+                "issue": issue_roof(dom, T, n_cus, clock_ghz, kern[dom]["avg_ms"]) if mode == "f16x2" and not strong else None,
                 "algorithmic_bytes_per_launch": rf["hbm"]["bytes_per_launch"], "flops_per_launch": rf["mfma"]["flops_per_launch"],
                 "t_hbm_roof_us": rf["t_hbm_us"], "t_mfma_roof_us": rf["t_mfma_us"],
                 "hbm": rf["hbm"], "mfma": rf["mfma"],
@@ -784,7 +869,9 @@ def main():
                          "operands once) / 8 TB/s; mfma = algorithmic fp32-class flops against " +
                          (f"{BF16_MFMA_PEAK_TFLOPS:.0f} / {terms} TFLOP/s (the kernel runs them as {terms}-term {mode} split products on the "
                           "16-bit matrix cores)" if terms else "the 157.3 TFLOP/s fp32 matrix pipe") +
-                         "; `bound` is the roof with the larger time, `frac` is against it"),
+                         "; `bound` is the roof with the larger time, `frac` is against it; `issue` is the third roof — the instruction "
+                         "issue time of the shipped code object's tile loop at the measured clock — which is what paces this kernel "
+                         "in practice (its frac is the one to read for kernel quality)"),
                 "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r*_pmc_traffic.json; null when no file was measured on these kernel sources)",
                 "timed_with": "hipEvent pairs on the launch stream around this kernel's launches inside the timed region"}
             result["kernels"] = kern

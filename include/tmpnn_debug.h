@@ -35,6 +35,10 @@ int tmpnn_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t
  * `sink` (>= 256 floats) keeps the result live. */
 int tmpnn_clock_probe(int blocks, int iters, uint64_t *out, float *sink, tmpnn_stream_t stream);
 
+/* n dependent launches of a do-nothing kernel (grid x block, lds_bytes of dynamic LDS; dirty_floats > 0: each launch writes that
+ * many floats of buf): this box's price of a kernel boundary, to compare with the gaps of the real forward (tools/gap_probe.py). */
+int tmpnn_launch_probe(int n, int grid, int block, int lds_bytes, float *buf, int dirty_floats, tmpnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

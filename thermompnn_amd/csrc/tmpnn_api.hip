@@ -521,6 +521,23 @@ extern "C" int tmpnn_clock_probe(int blocks, int iters, uint64_t *out, float *si
     return launch_clock_probe(blocks, iters, (unsigned long long *)out, sink, (hipStream_t)stream);
 }
 
+// measurement hook: n dependent launches of a kernel that does (almost) nothing — the box's own price of a kernel boundary, to set
+// beside the end-to-start gaps of the real 19-launch forward (tools/gap_probe.py). dirty_floats > 0: every launch also writes that
+// many floats of `buf` (dirty lines for the boundary's write-back); lds_bytes: dynamic LDS per workgroup (residency as the real kernels).
+__global__ void launch_probe_kernel(float *buf, int dirty_floats, int k) {
+    extern __shared__ float probe_lds[];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dirty_floats; i += gridDim.x * blockDim.x) buf[i] = (float)k;
+    if (dirty_floats < 0) probe_lds[threadIdx.x] = 0.f;
+}
+extern "C" int tmpnn_launch_probe(int n, int grid, int block, int lds_bytes, float *buf, int dirty_floats, tmpnn_stream_t stream) {
+    REQUIRE(n > 0 && grid > 0 && block > 0 && block <= 1024 && lds_bytes >= 0 && lds_bytes <= 160 * 1024, "launch_probe: bad argument");
+    REQUIRE(dirty_floats <= 0 || buf, "launch_probe: dirty_floats without a buffer");
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(launch_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int k = 0; k < n; ++k) launch_probe_kernel<<<grid, block, lds_bytes, (hipStream_t)stream>>>(buf, dirty_floats, k);
+    return tm_check_launch("launch_probe");
+}
+
 extern "C" int tmpnn_dec_layer(const tmpnn_weights_t *w, int layer, const float *h_V_in, float *h_V_out, const float *h_E,
                                const int32_t *E_idx, const int32_t *S, const float *mask, int64_t T, void *workspace,
                                size_t workspace_bytes, tmpnn_stream_t stream) {
@@ -572,8 +589,8 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     if (max_len > 8192) return tm_set_error(TMPNN_E_UNSUPPORTED, "ssm_forward: max_len %d > 8192", max_len);
     hipStream_t st = (hipStream_t)stream;
     const TmModeScope scope(w);
-    if (status_opt && hipMemsetAsync(status_opt, 0, sizeof(int32_t), st) != hipSuccess)
-        return tm_set_error(TMPNN_E_LAUNCH, "ssm_forward: status memset failed");
+    // (no memset launch for status_opt — hipMemsetAsync of 4 bytes is a 5.4 us fill kernel in front of a 180 us single-protein
+    //  forward: the k-NN kernel zeroes the word, and the LAST kernel flags what the k-NN kernel found, see KnnInit / HeadArgs)
 
     LayerWs ws;
     Carver c{nullptr, 0};
@@ -591,7 +608,7 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     // h_V starts at zero (:1228): the k-NN kernel writes that state and its message projection [b1 | 0] as it goes, and
     // node_update of every layer writes the projection the next message pass needs into ws.P — 18 launches per forward
     // (28 when every projection and the zero state are launches of their own)
-    TRY(launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, status_opt, st, KnnInit{hV[0], ws.P, w->enc[0].b1}));
+    TRY(launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, nullptr, st, KnnInit{hV[0], ws.P, w->enc[0].b1, status_opt}));
     TRY(launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, hE, nullptr, st));
     for (int l = 0; l < 3; ++l) {
         const NodeProj next = l < 2 ? enc_msg_proj(w, l + 1, ws.P) : dec_msg_proj(w, 0, ws.P, S);
@@ -601,10 +618,10 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
         const NodeProj next = dec_msg_proj(w, l < 2 ? l + 1 : 2, ws.P, S);
         TRY(run_dec_layer(w, l, hV[l], hV[l + 1], hE, E_idx, S, mask, T, ws, true, l < 2 ? &next : nullptr, st));
     }
-    if (ddg) TRY(launch_head(w, hV[3], hV[2], S, T, ddg, nullptr, status_opt, st));
-    if (log_probs_opt) TRY(launch_log_probs(w, hV[3], T, log_probs_opt, status_opt, st));
+    if (ddg) TRY(launch_head(w, hV[3], hV[2], S, T, ddg, nullptr, status_opt, st, E_idx));
+    if (log_probs_opt) TRY(launch_log_probs(w, hV[3], T, log_probs_opt, status_opt, st, ddg ? nullptr : E_idx));
     // hidden states only: neither of the kernels above has looked at the last decoder state (a poisoned value anywhere upstream
     // has reached it through its neighbours by now)
-    if (!ddg && !log_probs_opt && hidden_opt) TRY(launch_range_check(hV[3], T * TMPNN_HID, status_opt, st));
+    if (!ddg && !log_probs_opt && hidden_opt) TRY(launch_range_check(hV[3], T * TMPNN_HID, status_opt, st, E_idx, T));
     return TMPNN_OK;
 }

@@ -335,6 +335,7 @@ __global__ __launch_bounds__(TM_THREADS, NS == 8 ? 4 : 8) void knn_kernel(const 
     __shared__ unsigned s_sel[NS > 0 ? 4 : 1][64][2];        // compaction slots of knn_row_sel, one set per wavefront
     const int lane = tm_tid() & 63, wv = tm_wave(tm_tid());
     float *d = knn_lds + (size_t)wv * (max_len + (max_len >> 6) + 1);
+    if (init.status_zero && tm_bid() == 0 && tm_tid() == 0) *init.status_zero = 0;   // (nothing in this launch ORs into it: status == nullptr)
 
     for (int i = tm_bid() * 4 + wv; i < T; i += tm_nblk() * 4) {
         if (init.hV0) {      // the fused forward: this residue's all-zero initial state and its projection (W . 0 + b = b exactly)

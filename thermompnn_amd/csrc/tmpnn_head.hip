@@ -21,6 +21,9 @@ struct HeadArgs {
     float *ddg, *z_opt;
     int T;
     int32_t *status;                      // may be null: TMPNN_STATUS_RANGE is OR-ed in when a ddG is not finite
+    const int32_t *maxlen_probe;          // fused forward: E_idx [T,48]; slot 0 < 0 marks a row the k-NN kernel left empty because its
+                                          // protein is longer than max_len -> TMPNN_STATUS_MAXLEN (the k-NN kernel zeroes the word and
+                                          // therefore cannot OR into it itself: no memset launch in front of the forward)
     const char *img[12];                  // f16 fragment images of the 12 GEMM units (WImg, tmpnn_internal.h) or all null
 };
 
@@ -39,6 +42,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void head_kernel(HeadArgs a) {
     for (int tile = tm_bid(); tile < n_tiles; tile += tm_nblk()) {
         const int r0 = tile * ROWS, rows = min(ROWS, a.T - r0);
         if (tid < ROWS) s_S[tid] = tid < rows ? a.S[r0 + tid] : 0;
+        if (a.maxlen_probe && a.status && tid < rows && a.maxlen_probe[(size_t)(r0 + tid) * TM_KS] < 0) atomicOr(a.status, TMPNN_STATUS_MAXLEN);
         load_tile<NRB>(tX[0], a.hA + (size_t)r0 * TM_H, rows, tid);
         load_tile<NRB>(tX[1], a.hB + (size_t)r0 * TM_H, rows, tid);
         if (a.status) {     // the ReLUs of both_out map NaN to 0: a poisoned decoder state must be flagged at the input
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
     for (; tile < n_tiles; tile += tm_nblk()) {
         const int r0 = tile * ROWS, rows = min(ROWS, a.T - r0);
         if (tid < ROWS) s_S[tid] = tid < rows ? a.S[r0 + tid] : 0;
+        if (a.maxlen_probe && a.status && tid < rows && a.maxlen_probe[(size_t)(r0 + tid) * TM_KS] < 0) atomicOr(a.status, TMPNN_STATUS_MAXLEN);
         for (int idx = tid; idx < ROWS * 32; idx += 512) {      // x = [h_last | h_prev | W_s[S]] -> planes
             const int row = idx >> 5, c = idx & 31;
             const bool ok = row < rows;
@@ -323,10 +328,12 @@ __global__ __launch_bounds__(512, 2) void head8_split_kernel(HeadArgs a) {
 // log_softmax(W_out h + b): one wavefront per residue, lane a < 21 owns logit a.
 __global__ __launch_bounds__(TM_THREADS) void log_probs_kernel(const float *__restrict__ W, const float *__restrict__ b,
                                                                const float *__restrict__ h, int T,
-                                                               float *__restrict__ out, int32_t *__restrict__ status) {
+                                                               float *__restrict__ out, int32_t *__restrict__ status,
+                                                               const int32_t *__restrict__ maxlen_probe) {
     const int lane = tm_tid() & 63, wv = tm_tid() >> 6;
     for (int t = tm_bid() * 4 + wv; t < T; t += tm_nblk() * 4) {
         float logit = -INFINITY;
+        if (maxlen_probe && status && lane == 0 && maxlen_probe[(size_t)t * TM_KS] < 0) atomicOr(status, TMPNN_STATUS_MAXLEN);   // see HeadArgs
         if (status) {      // poisoned input row -> flag (raw-bit test on the loaded values, see tm_nonfinite_bits)
             const unsigned *ur = reinterpret_cast<const unsigned *>(h + (size_t)t * TM_H);
             if (tm_nonfinite_bits(ur[lane]) || tm_nonfinite_bits(ur[lane + 64])) atomicOr(status, TMPNN_STATUS_RANGE);
@@ -392,9 +399,9 @@ int launch_prep_tables(tmpnn_weights *w, hipStream_t st) {
 }
 
 int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg,
-                float *z_opt, int32_t *status, hipStream_t st) {
+                float *z_opt, int32_t *status, hipStream_t st, const int32_t *maxlen_probe) {
     HeadArgs a{w->conv_center, w->conv_b, w->mlp_w[0], w->mlp_b[0], w->mlp_w[1], w->mlp_b[1], w->mlp_w[2], w->mlp_b[2],
-               w->ddg_w, w->ddg_b, w->Ws_w, hA, hB, S, ddg, z_opt, (int)T, status, {}};
+               w->ddg_w, w->ddg_b, w->Ws_w, hA, hB, S, ddg, z_opt, (int)T, status, maxlen_probe, {}};
     bool have_img = tm_matmul_mode() == TM_MM_F16X2;
     for (int u = 0; u < 12 && have_img; ++u) {
         a.img[u] = tm_find_wimg(u < 9 ? w->conv_center + (size_t)128 * (u / 3) * 384 + 128 * (u % 3) : w->mlp_w[0] + 128 * (u - 9));
@@ -432,16 +439,24 @@ int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const 
     return tm_check_launch("ddg_head");
 }
 
-int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, int32_t *status, hipStream_t st) {
+int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, int32_t *status, hipStream_t st,
+                     const int32_t *maxlen_probe) {
     const int64_t blocks = (T + 3) / 4, cap = (int64_t)tm_num_cus() * 8;
-    { tm_prof_begin("log_probs", st); log_probs_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Wout_w, w->Wout_b, h, (int)T, out, status); tm_prof_end(st); }
+    { tm_prof_begin("log_probs", st); log_probs_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Wout_w, w->Wout_b, h, (int)T, out, status, maxlen_probe); tm_prof_end(st); }
     return tm_check_launch("log_probs");
 }
 
 // A forward that returns hidden states only (no ddG head, no log-probabilities) has no kernel that looks at them: this one does.
-__global__ __launch_bounds__(TM_THREADS) void range_check_kernel(const unsigned *__restrict__ x, int64_t n4, int32_t *__restrict__ status) {
+__global__ __launch_bounds__(TM_THREADS) void range_check_kernel(const unsigned *__restrict__ x, int64_t n4, int32_t *__restrict__ status,
+                                                                 const int32_t *__restrict__ maxlen_probe, int64_t T) {
     typedef unsigned uv4 __attribute__((ext_vector_type(4)));
     bool bad = false;
+    if (maxlen_probe) {                                          // see HeadArgs::maxlen_probe
+        bool longer = false;
+        for (int64_t t = (int64_t)tm_bid() * TM_THREADS + tm_tid(); t < T; t += (int64_t)tm_nblk() * TM_THREADS)
+            longer = longer || maxlen_probe[t * TM_KS] < 0;
+        if (longer) atomicOr(status, TMPNN_STATUS_MAXLEN);
+    }
     for (int64_t i = (int64_t)tm_bid() * TM_THREADS + tm_tid(); i < n4; i += (int64_t)tm_nblk() * TM_THREADS) {
         const uv4 v = reinterpret_cast<const uv4 *>(x)[i];
         bad = bad || tm_nonfinite_bits(v.x) || tm_nonfinite_bits(v.y) || tm_nonfinite_bits(v.z) || tm_nonfinite_bits(v.w);
@@ -449,10 +464,10 @@ __global__ __launch_bounds__(TM_THREADS) void range_check_kernel(const unsigned 
     if (bad) atomicOr(status, TMPNN_STATUS_RANGE);
 }
 
-int launch_range_check(const float *x, int64_t n, int32_t *status, hipStream_t st) {
+int launch_range_check(const float *x, int64_t n, int32_t *status, hipStream_t st, const int32_t *maxlen_probe, int64_t T) {
     if (!status || n <= 0) return TMPNN_OK;
     const int64_t n4 = n / 4, blocks = (n4 + TM_THREADS - 1) / TM_THREADS, cap = (int64_t)tm_num_cus() * 4;     // n is a multiple of 128 here
-    range_check_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(reinterpret_cast<const unsigned *>(x), n4, status);
+    range_check_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(reinterpret_cast<const unsigned *>(x), n4, status, maxlen_probe, T);
     return tm_check_launch("range_check");
 }
 

@@ -58,9 +58,11 @@ void tm_prof_end(hipStream_t st);
 // Optional extra of the fused forward: the k-NN kernel (one wavefront per residue) also writes the residue's all-zero initial
 // node state hV0[t, 0:128] and its message projection P[t] = [ba | 0] (what node_proj of a zero state gives, exactly) —
 // two launches (a memset and a fill) fewer per forward.
-struct KnnInit { float *hV0; float *P; const float *ba; };
+// fused forward: the k-NN kernel writes the zero state + first projection and ZEROES the caller's status word (workgroup 0; it
+// then must not OR into that word itself — rows of an over-long protein are flagged by the last kernel, HeadArgs::maxlen_probe)
+struct KnnInit { float *hV0; float *P; const float *ba; int32_t *status_zero; };
 int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, int max_len, int K,
-               int32_t *E_idx, float *D_nb, int32_t *status, hipStream_t st, KnnInit init = KnnInit{nullptr, nullptr, nullptr});
+               int32_t *E_idx, float *D_nb, int32_t *status, hipStream_t st, KnnInit init = KnnInit{nullptr, nullptr, nullptr, nullptr});
 int launch_centrality(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, float radius,
                       int32_t *out, hipStream_t st);
 int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx, const int32_t *cenc,
@@ -95,10 +97,12 @@ int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_i
 
 // tmpnn_head.hip
 int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg,
-                float *z_opt, int32_t *status, hipStream_t st);
-int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, int32_t *status, hipStream_t st);
+                float *z_opt, int32_t *status, hipStream_t st, const int32_t *maxlen_probe = nullptr);
+int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, int32_t *status, hipStream_t st,
+                     const int32_t *maxlen_probe = nullptr);
 int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float *hS, hipStream_t st);
-int launch_range_check(const float *x, int64_t n, int32_t *status, hipStream_t st);   // ORs TMPNN_STATUS_RANGE if any x is inf / NaN
+int launch_range_check(const float *x, int64_t n, int32_t *status, hipStream_t st, const int32_t *maxlen_probe = nullptr,
+                       int64_t T = 0);   // ORs TMPNN_STATUS_RANGE if any x is inf / NaN (+ the MAXLEN probe of the fused forward)
 int launch_prep_tables(tmpnn_weights *w, hipStream_t st);
 
 int launch_clock_probe(int blocks, int iters, unsigned long long *out, float *sink, hipStream_t st);
