@@ -34,7 +34,8 @@ WEIGHT_SEED = 0
 # further weight sets through the SAME imported reference: (fixture suffix, seed, style). The released checkpoints are absent
 # from the mount, so the only guard for the split-precision accuracy margin is a second Xavier draw and a deliberately heavy
 # ("hot") draw: matrices x 3, biases x 5, LayerNorm gamma in [-2, 2] (thermompnn_amd.weights._draw).
-EXTRA_WEIGHT_SETS = (("w1", 1, "xavier"), ("hot", 2, "hot"))
+# ("wide", round 4): matrices x 8, N(0, 0.5) biases — Linear outputs of 1e3..1e4, the upper end of the fp16 range the f16x2 path carries.
+EXTRA_WEIGHT_SETS = (("w1", 1, "xavier"), ("hot", 2, "hot"), ("wide", 3, "wide"))
 
 
 class AD(dict):

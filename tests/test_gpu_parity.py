@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden, tol_scale, weights_for_case
+from conftest import GOLDEN, HOT_F64_FACTOR, is_hot, load_golden, oracle_trace_f64, tol_scale, weights_for_case
 
 pytestmark = pytest.mark.gpu
 
@@ -15,7 +15,7 @@ TOL_DDG = 1e-4            # kcal/mol; BASELINE.json north_star
 CASES = ["2OCJ_A", "2OCJ_A_gap", "2OCJ_AB", "syn_L32", "syn_L256", "syn_L256_s1"]
 # the same proteins through two more weight sets of the imported reference (make_golden.EXTRA_WEIGHT_SETS): a second Xavier draw
 # and the heavy "hot" draw (matrices x 3, biases x 5, LayerNorm gamma in [-2, 2]; tolerances scale with the tensors, conftest.tol_scale)
-EXTRA_CASES = ["2OCJ_A_w1", "syn_L32_w1", "2OCJ_A_hot", "syn_L32_hot"]
+EXTRA_CASES = ["2OCJ_A_w1", "syn_L32_w1", "2OCJ_A_hot", "syn_L32_hot", "2OCJ_A_wide", "syn_L32_wide"]   # wide: Linear outputs to 1e4
 _ENGINES = {}
 WORST = {}          # (precision, quantity) -> worst |hip - reference| / tolerance seen in this session (written to gpurun_out/)
 
@@ -29,12 +29,32 @@ def engine_for(g, precision=None):
     return _ENGINES[key]
 
 
-def close(got, want, tol, g, what, prec):
-    """assert_allclose with the tolerance scaled for the hot draw; records the worst error / tolerance ratio."""
-    atol = tol * tol_scale(g, want)
-    err = float(np.nanmax(np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64)))) if np.size(want) else 0.0
+def close(got, want, tol, g, what, prec, f64=None):
+    """Xavier draws: |got - want| <= tol, absolute (north_star's 1e-5 / 1e-4). Hot draw (activations up to 1e2): the tensors
+    are one to two orders larger and ``want`` — the reference's own fp32 evaluation — is itself 0.3-0.5 of any sensible absolute
+    line away from the truth, so the criterion is distance to the FLOAT64 truth ``f64`` (conftest.oracle_trace_f64, same graph):
+        |got - f64| <= max(2.5 x max|want - f64|, tol)            per tensor
+    i.e. the HIP path may be at most 2.5 x as far from the truth as the reference is. The ratios against
+    the round-2 (divisor 4) and round-3 (divisor 3) scaled absolute lines are still recorded in parity_worst_errors.json."""
+    got64, want64 = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    err = float(np.nanmax(np.abs(got64 - want64))) if np.size(want) else 0.0
     style = str(g["weight_style"]) if "weight_style" in g else "xavier"
     k = f"{prec}/{style}/{what}"
+    if is_hot(g) and f64 is not None:
+        truth = np.asarray(f64, dtype=np.float64)
+        ref_err = float(np.nanmax(np.abs(want64 - truth))) if np.size(want) else 0.0
+        hip_err = float(np.nanmax(np.abs(got64 - truth))) if np.size(want) else 0.0
+        bound = max(HOT_F64_FACTOR * ref_err, tol)
+        line4 = tol * max(1.0, float(np.nanmax(np.abs(want64))) / 4.0)
+        rec = {"ratio": hip_err / bound, "abs_err_vs_f64": hip_err, "reference_abs_err_vs_f64": ref_err, "bound": bound,
+               "hip_over_reference_distance": hip_err / ref_err if ref_err > 0 else None,
+               "vs_reference_ratio_divisor4_line": err / line4, "vs_reference_ratio_divisor3_line": err / (line4 * 4.0 / 3.0),
+               "abs_err_vs_reference": err, "criterion": "float64 truth, 2.5 x the reference's own distance"}
+        if rec["ratio"] > WORST.get(k, {"ratio": -1})["ratio"]:
+            WORST[k] = rec
+        assert hip_err <= bound, f"{what}: |hip - f64| = {hip_err:.3e} > {bound:.3e} (reference is {ref_err:.3e} from the truth)"
+        return
+    atol = tol * tol_scale(g, want)
     if err / atol > WORST.get(k, {"ratio": -1})["ratio"]:
         WORST[k] = {"ratio": err / atol, "abs_err": err, "atol": atol}
     np.testing.assert_allclose(got, want, atol=atol, rtol=0, err_msg=what)
@@ -159,37 +179,40 @@ def check_stagewise(g, engine, synthetic_weights):
     assert (np.diff(dn[:, :Keff], axis=1) >= 0).all()                     # sorted ascending like torch.topk
     # everything downstream is compared on the SAME graph, slot by slot
     tr = oracle_trace(synthetic_weights, g, ei[:, :Keff])
+    t64 = oracle_trace_f64(g, ei[:, :Keff]) if is_hot(g) else None        # the float64 truth on the same graph (hot draws)
+    f64 = lambda name: None if t64 is None else t64[name]
+    f64_edges = lambda name: None if t64 is None else align(t64[name], t64["E_idx"], tr[name], tr["E_idx"], valid)[0]
 
     # K1: featurizer output E (LayerNorm) and h_E = W_e E + b
     h_E, E = engine.edge_featurize(p["X"], p["ridx"], p["cenc"], E_idx, D_nb, want_E=True)
     a, b = align(E.cpu().numpy(), ei, tr["E"], tr["E_idx"], valid)
-    close(a, b, TOL_INTERMEDIATE, g, "E", prec)
+    close(a, b, TOL_INTERMEDIATE, g, "E", prec, f64_edges("E"))
     a, b = align(h_E.cpu().numpy(), ei, tr["h_E0"], tr["E_idx"], valid)
-    close(a, b, TOL_INTERMEDIATE, g, "h_E0", prec)
+    close(a, b, TOL_INTERMEDIATE, g, "h_E0", prec, f64_edges("h_E0"))
     assert (h_E.cpu().numpy()[:, Keff:] == 0).all()
 
     # K2/K3: encoder
     h_V = torch.zeros((L, 128), device="cuda:0")
     for l in range(3):
         engine.enc_layer(l, h_V, h_E, E_idx, p["mask"])
-        close(h_V.cpu().numpy(), tr[f"hV_enc{l + 1}"], TOL_INTERMEDIATE, g, f"hV_enc{l + 1}", prec)
+        close(h_V.cpu().numpy(), tr[f"hV_enc{l + 1}"], TOL_INTERMEDIATE, g, f"hV_enc{l + 1}", prec, f64(f"hV_enc{l + 1}"))
     a, b = align(h_E.cpu().numpy(), ei, tr["h_E_final"], tr["E_idx"], valid)
-    close(a, b, TOL_INTERMEDIATE, g, "h_E_final", prec)
+    close(a, b, TOL_INTERMEDIATE, g, "h_E_final", prec, f64_edges("h_E_final"))
 
     # K4: decoder
     hs = []
     for l in range(3):
         h_V = engine.dec_layer(l, h_V, h_E, E_idx, p["S"], p["mask"])
         hs.append(h_V)
-        close(h_V.cpu().numpy(), tr[f"hV_dec{l + 1}"], TOL_INTERMEDIATE, g, f"hV_dec{l + 1}", prec)
+        close(h_V.cpu().numpy(), tr[f"hV_dec{l + 1}"], TOL_INTERMEDIATE, g, f"hV_dec{l + 1}", prec, f64(f"hV_dec{l + 1}"))
     assert (hs[2].cpu().numpy()[g["mask"] == 0] == 0).all()
 
     # epilogues: W_s embedding, logits, head
     np.testing.assert_array_equal(engine.seq_embed(p["S"]).cpu().numpy(), tr["h_S"])
-    close(engine.log_probs(hs[2]).cpu().numpy(), tr["log_probs"], TOL_INTERMEDIATE, g, "log_probs", prec)
+    close(engine.log_probs(hs[2]).cpu().numpy(), tr["log_probs"], TOL_INTERMEDIATE, g, "log_probs", prec, f64("log_probs"))
     ddg, z = engine.ddg_head(hs[2], hs[1], p["S"], want_z=True)
-    close(z.cpu().numpy(), tr["z"], TOL_INTERMEDIATE, g, "z", prec)
-    close(ddg.cpu().numpy(), tr["ddg"], TOL_DDG, g, "ddg", prec)
+    close(z.cpu().numpy(), tr["z"], TOL_INTERMEDIATE, g, "z", prec, f64("z"))
+    close(ddg.cpu().numpy(), tr["ddg"], TOL_DDG, g, "ddg", prec, f64("ddg"))
 
 
 @pytest.mark.parametrize("case", CASES + EXTRA_CASES)
@@ -216,14 +239,16 @@ def check_fused_forward(case, engine, synthetic_weights):
         g = dict(g, hV_dec3=tr["hV_dec3"], log_probs=tr["log_probs"], ddg=tr["ddg"][:, :20])
     hid = res["hidden"].cpu().numpy()
     prec = engine.precision + "/fused"
-    close(hid[2], g["hV_dec3"], TOL_INTERMEDIATE, g, "hV_dec3", prec)
+    t64 = oracle_trace_f64(g, ei[:, :Keff]) if is_hot(g) else None        # hot draws: distance to the float64 truth (close())
+    f64 = lambda name: None if t64 is None else t64[name]
+    close(hid[2], g["hV_dec3"], TOL_INTERMEDIATE, g, "hV_dec3", prec, f64("hV_dec3"))
     if "hV_dec1" in g:
-        close(hid[0], g["hV_dec1"], TOL_INTERMEDIATE, g, "hV_dec1", prec)
-        close(hid[1], g["hV_dec2"], TOL_INTERMEDIATE, g, "hV_dec2", prec)
-    close(res["log_probs"].cpu().numpy(), g["log_probs"], TOL_INTERMEDIATE, g, "log_probs", prec)
+        close(hid[0], g["hV_dec1"], TOL_INTERMEDIATE, g, "hV_dec1", prec, f64("hV_dec1"))
+        close(hid[1], g["hV_dec2"], TOL_INTERMEDIATE, g, "hV_dec2", prec, f64("hV_dec2"))
+    close(res["log_probs"].cpu().numpy(), g["log_probs"], TOL_INTERMEDIATE, g, "log_probs", prec, f64("log_probs"))
     ddg = res["ddg"].cpu().numpy()
     have = ~np.isnan(g["ddg"][:, 0])
-    close(ddg[have][:, :20], g["ddg"][have], TOL_DDG, g, "ddg", prec)
+    close(ddg[have][:, :20], g["ddg"][have], TOL_DDG, g, "ddg", prec, None if t64 is None else t64["ddg"][have][:, :20])
     wt = g["S"].astype(np.int64)
     assert (ddg[np.arange(len(wt)), wt] == 0).all()                       # wt -> wt rows are exactly 0
 

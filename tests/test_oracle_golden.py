@@ -8,7 +8,8 @@ from conftest import load_golden, tol_scale, weights_for_case
 from oracle import thermompnn_oracle as orc
 
 CASES = ["2OCJ_A", "2OCJ_A_gap", "2OCJ_AB", "syn_L32", "syn_L256", "syn_L256_s1",
-         "2OCJ_A_w1", "syn_L32_w1", "2OCJ_A_hot", "syn_L32_hot"]      # _w1: second Xavier draw; _hot: heavy draw (conftest.tol_scale)
+         "2OCJ_A_w1", "syn_L32_w1", "2OCJ_A_hot", "syn_L32_hot",      # _w1: second Xavier draw; _hot: heavy draw (conftest.tol_scale)
+         "2OCJ_A_wide", "syn_L32_wide"]                               # _wide: Linear outputs of 1e3..1e4 (the top of the fp16 range)
 TOL_INTERMEDIATE = 1e-5   # abs, SURVEY §8c
 TOL_DDG = 1e-4            # kcal/mol, BASELINE.json north_star
 
@@ -31,7 +32,7 @@ def neighbour_sets_equal(a, b, mask):
 def test_oracle_matches_reference(case):
     g = load_golden(case)
     synthetic_weights = weights_for_case(g)
-    assert (int(g["weight_seed"]), str(g["weight_style"])) == {"w1": (1, "xavier"), "hot": (2, "hot")}.get(case.rsplit("_", 1)[-1], (0, "xavier"))
+    assert (int(g["weight_seed"]), str(g["weight_style"])) == {"w1": (1, "xavier"), "hot": (2, "hot"), "wide": (3, "wide")}.get(case.rsplit("_", 1)[-1], (0, "xavier"))
     X, S, mask, chain_M, ridx, cenc = inputs(g)
     tr = {}
     with torch.no_grad():
@@ -90,7 +91,7 @@ def test_hot_tolerance_sits_above_the_reference_own_rounding():
     fp32 tensors (the goldens) and a float64 evaluation of the same network (the oracle run in float64 on the same weights). The
     line is 2.5-7 x that distance for every compared tensor — neither inside the reference's noise nor an order of magnitude
     loose."""
-    cases = {c: load_golden(c) for c in ("2OCJ_A_hot", "syn_L32_hot")}
+    cases = {c: load_golden(c) for c in ("2OCJ_A_hot", "syn_L32_hot", "2OCJ_A_wide", "syn_L32_wide")}
     orig_float, orig_default = torch.Tensor.float, torch.get_default_dtype()
     torch.Tensor.float = lambda self, *a, **k: self.double()          # the oracle's explicit .float() casts -> float64
     torch.set_default_dtype(torch.float64)

@@ -88,15 +88,18 @@ def transfer_param_shapes() -> "OrderedDict[str, tuple]":
     return s
 
 
-STYLES = ("xavier", "hot")
+STYLES = ("xavier", "hot", "wide")
 
 
 def _draw(rng: np.random.Generator, name: str, shape: tuple, style: str = "xavier") -> np.ndarray:
     """``style`` 'xavier': Xavier-uniform matrices, N(0, 0.02) biases, LayerNorm gamma 1 +- 0.1 / beta +- 0.1.
     'hot': a deliberately heavy draw for the accuracy margin of the split-precision kernels — matrices x 3, biases x 5,
     LayerNorm gamma uniform in [-2, 2] and beta in [-0.5, 0.5]: activations one to two orders of magnitude above the
-    Xavier draw's, still finite in fp32 through the reference."""
-    hot = style == "hot"
+    Xavier draw's, still finite in fp32 through the reference.
+    'wide': the same LayerNorm parameters with matrices x 8 and N(0, 0.5) biases — Linear outputs reach 1e3..1e4 through the
+    reference (ddG of +-1.4e4): the upper end of what the f16x2 matrix-core path can carry (fp16 ends at 65504); tests its
+    ACCURACY near the range limit, not just the overflow flag."""
+    hot = style in ("hot", "wide")
     leaf = name.rsplit(".", 1)[-1]
     if name.startswith("ddg_out"):
         return np.full(shape, 1.7 if leaf == "weight" else -0.3, dtype=np.float32)
@@ -105,10 +108,10 @@ def _draw(rng: np.random.Generator, name: str, shape: tuple, style: str = "xavie
             return (rng.uniform(-2.0, 2.0, shape) if hot else 1.0 + rng.uniform(-0.1, 0.1, shape)).astype(np.float32)
         return rng.uniform(-0.5, 0.5, shape).astype(np.float32) if hot else rng.uniform(-0.1, 0.1, shape).astype(np.float32)
     if leaf == "bias":
-        return rng.normal(0.0, 0.1 if hot else 0.02, shape).astype(np.float32)
+        return rng.normal(0.0, 0.5 if style == "wide" else 0.1 if hot else 0.02, shape).astype(np.float32)
     bound = math.sqrt(6.0 / (shape[0] + shape[1]))        # Xavier-uniform (protein_mpnn_utils.py:1217-1219); conv taps: all nine non-zero
     if hot:
-        bound *= 3.0
+        bound *= 8.0 if style == "wide" else 3.0
     return rng.uniform(-bound, bound, shape).astype(np.float32)
 
 
