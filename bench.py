@@ -824,6 +824,16 @@ def main():
             result["excl_collective"] = {"value": 200000 * args.steps / dt_nc, "ms_per_step": dt_nc / args.steps * 1e3,
                                          "note": "forward on every rank's shard only: no all-gather, no selection"}
         result["checksum_listed"] = float(picked[0].double().sum().item()) if picked[0] is not None else None
+    elif grouped:
+        # weak scaling too: the same steps without the per-step exchange, so a scaling curve separates compute from the collective
+        for _ in range(2):
+            step(gather=False)
+        barrier()
+        dt_nc, _, _ = timed(args.steps, False, False)
+        result["excl_collective"] = {"value": units_per_step * args.steps / dt_nc, "ms_per_step": dt_nc / args.steps * 1e3,
+                                     "collective_cost_ms_per_step": (dt - dt_nc) / args.steps * 1e3,
+                                     "note": "forward on every rank only: no all-gather of the ddG tables (the timed `value` includes it, "
+                                             "asynchronous and overlapped with the next step)"}
 
     if rank == 0:
         T = T_loc

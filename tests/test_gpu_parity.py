@@ -834,6 +834,7 @@ def test_two_rank_bench_and_cli(tmp_path):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["preds_per_step"] == 2 * 2 * 256 * 20
     assert d["collective"]["ranks_seen"] == 2 and d["collective"]["world_size"] == 2
+    assert d["excl_collective"]["value"] > 0 and d["excl_collective"]["ms_per_step"] > 0      # weak mode separates compute from the exchange too
     from thermompnn_amd import ssm_scan
     pdbs = [os.path.join(GOLDEN, "2OCJ.pdb"), os.path.join(GOLDEN, "2OCJ_gap_chainA.pdb")]
     single = ssm_scan.main(pdbs + ["--synthetic_weights", "0", "--centrality", "--out", str(tmp_path / "one.csv")])
