@@ -180,6 +180,20 @@ int tmpnn_ddg_head(const tmpnn_weights_t *w, const float *hV_last, const float *
                    const int32_t *S, int64_t T, float *ddg, float *z_opt, int32_t *status_opt,
                    tmpnn_stream_t stream);
 
+/* The same head for ANY configuration the reference constructor accepts (transfer_model.py:45-73): num_final_layers
+ * n_final in 0..3 (hidden[0] = last decoder state, hidden[1] the one before, ... as all_mpnn_hid[:n] :84-85), LightAttention
+ * on (conv_w [D0, D0, 9] + conv_b [D0], D0 = 128 n_final + 128; only the centre tap acts on a length-1 sequence) or off
+ * (conv_w = conv_b = NULL, :106-108), any hidden_dims: dims[0] = D0, dims[1..n_layers-1] = hidden_dims, dims[n_layers] = 21;
+ * mlp_w[l] [dims[l+1], dims[l]], mlp_b[l] = both_out's Linear l (ReLU in FRONT of each, :69-71). hidden, mlp_w, mlp_b, dims are
+ * HOST arrays (of device pointers / ints); everything they point to, S and the outputs are device memory. ddg [T,21] as
+ * tmpnn_ddg_head; z_opt [T,21]. The released configuration runs the specialised kernels behind tmpnn_ddg_head /
+ * tmpnn_ssm_forward; this entry keeps retrained heads runnable (fp32 matrix cores, operands from global memory). */
+size_t tmpnn_head_generic_workspace_bytes(int64_t T, int n_final, int n_layers, const int32_t *dims);   /* 0 = bad dims */
+int tmpnn_ddg_head_generic(const float *const *hidden, int n_final, const float *Ws, const int32_t *S, int64_t T,
+                           const float *conv_w, const float *conv_b, int n_layers, const float *const *mlp_w,
+                           const float *const *mlp_b, const int32_t *dims, const float *ddg_w, const float *ddg_b, float *ddg,
+                           float *z_opt, void *workspace, size_t workspace_bytes, int32_t *status_opt, tmpnn_stream_t stream);
+
 /* ---- the fused path ------------------------------------------------------------------------------
  * Everything TransferModel.forward does on the device for a ragged batch of N proteins
  * (transfer_model.py:75-121 + protein_mpnn_utils.py:1222-1277), one call, ~30 launches on `stream`.

@@ -38,18 +38,24 @@ WEIGHT_SEED = 0
 EXTRA_WEIGHT_SETS = (("w1", 1, "xavier"), ("hot", 2, "hot"), ("wide", 3, "wide"))
 
 
+# Non-default TransferModel heads (the reference constructor accepts them, transfer_model.py:45-73; a retrained head may use
+# them): (fixture suffix, hidden_dims, num_final_layers, lightattn), seed-0 weights, 2OCJ chain A. Only z / ddG are stored.
+HEAD_CONFIGS = (("headA", [128, 48], 3, True), ("headB", [32], 1, False), ("headC", [], 0, True))
+
+
 class AD(dict):
     __getattr__ = dict.__getitem__
     __setattr__ = dict.__setitem__
 
 
-def build_reference_model(tmp, seed=WEIGHT_SEED, style="xavier"):
-    sd = synthetic_state_dict(seed, style=style)
+def build_reference_model(tmp, seed=WEIGHT_SEED, style="xavier", head=None):
+    sd = synthetic_state_dict(seed, style=style, head=head)
     mp, _ = split_transfer_state_dict(sd)
     os.makedirs(os.path.join(tmp, "vanilla_model_weights"), exist_ok=True)
     save_vanilla_checkpoint(os.path.join(tmp, "vanilla_model_weights", "v_48_020.pt"), mp, 48)
-    cfg = AD(model=AD(hidden_dims=[64, 32], subtract_mut=True, num_final_layers=2, freeze_weights=True,
-                      load_pretrained=True, lightattn=True), platform=AD(thermompnn_dir=tmp))
+    h = head or dict(hidden_dims=[64, 32], num_final_layers=2, lightattn=True)
+    cfg = AD(model=AD(hidden_dims=list(h["hidden_dims"]), subtract_mut=True, num_final_layers=h["num_final_layers"], freeze_weights=True,
+                      load_pretrained=True, lightattn=h["lightattn"]), platform=AD(thermompnn_dir=tmp))
     model = ref_tm.TransferModel(cfg)
     missing = model.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
@@ -77,8 +83,11 @@ def run_case(model, pdb, trace_level, seed=WEIGHT_SEED, style="xavier"):
         pred, _ = model([pdb], muts)
         hid, h_S, log_probs = mp(X, S, mask, chain_M, residue_idx, chain_enc, None)
         # head table z[L,21], one literal LightAttention + both_out evaluation per position
-        x = torch.cat([hid[0][0], hid[1][0], h_S[0]], -1)
-        z = torch.stack([model.both_out(model.light_attention(x[p][None, :, None], mask)) for p in range(x.shape[0])])
+        x = torch.cat([hid[k][0] for k in range(model.num_final_layers)] + [h_S[0]], -1)      # all_mpnn_hid[:n] + embed (:84-103)
+        if model.lightattn:
+            z = torch.stack([model.both_out(model.light_attention(x[p][None, :, None], mask)) for p in range(x.shape[0])])
+        else:
+            z = torch.stack([model.both_out(x[p]) for p in range(x.shape[0])])
     for h in hooks:
         h.remove()
 
@@ -151,6 +160,18 @@ def main():
                 np.savez_compressed(path, **out)
                 print(f"{base}_{suffix}: weights seed {seed} / {style} -> {os.path.getsize(path) / 1024:.0f} KiB, ddg range "
                       f"[{np.nanmin(out['ddg']):.3f}, {np.nanmax(out['ddg']):.3f}], max |activation| {out['max_abs_activation']:.1f}")
+
+        for suffix, hidden_dims, nfl, la in HEAD_CONFIGS:
+            head = dict(hidden_dims=hidden_dims, num_final_layers=nfl, lightattn=la)
+            with tempfile.TemporaryDirectory() as tmp3:
+                m3 = build_reference_model(tmp3, WEIGHT_SEED, "xavier", head)
+            full = run_case(m3, cases["2OCJ_A"][0], 1)
+            z3 = full["z"].reshape(full["z"].shape[0], -1)
+            path = os.path.join(HERE, f"2OCJ_A_{suffix}.npz")
+            np.savez_compressed(path, z=z3, ddg=full["ddg"], hidden_dims=np.array(hidden_dims, dtype=np.int64), num_final_layers=np.int64(nfl),
+                                lightattn=np.bool_(la), weight_seed=np.int64(WEIGHT_SEED), weight_style=np.array("xavier"))
+            print(f"2OCJ_A_{suffix}: head {hidden_dims} / {nfl} final layers / lightattn {la} -> {os.path.getsize(path) / 1024:.0f} KiB, "
+                  f"ddg range [{np.nanmin(full['ddg']):.3f}, {np.nanmax(full['ddg']):.3f}]")
 
         # model_utils.featurize (the training-flavour packer north_star names; /root/reference/model_utils.py:19-125) on a
         # batch of two single-chain proteins of different length (padding exercised; one chain per protein, so the

@@ -198,3 +198,50 @@ np.save({str(tmp_path / 'ddg.npy')!r}, np.array(vals, dtype=np.float32))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
     got = np.load(tmp_path / "ddg.npy").reshape(194, 20)
     np.testing.assert_allclose(got, load_golden("2OCJ_A")["ddg"][:, :20], atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("suffix", ["headA", "headB", "headC"])
+def test_non_default_head_configurations_match_the_reference(tmp_path, suffix):
+    """TransferModel configurations other than the released one — hidden_dims of other sizes / counts, num_final_layers 0..3,
+    lightattn on or off (transfer_model.py:45-73,84-108) — run through the generic head kernels (tmpnn_ddg_head_generic) behind the
+    unchanged `model(pdb, mutations)` API, against vectors the imported reference produced for those configurations."""
+    from conftest import load_golden
+    from thermompnn_amd import pdb_io, weights
+    from thermompnn_amd.ssm import mutation_objects
+    from thermompnn_amd.transfer_model import TransferModel
+    g = load_golden("2OCJ_A_" + suffix)
+    head = dict(hidden_dims=[int(x) for x in g["hidden_dims"]], num_final_layers=int(g["num_final_layers"]), lightattn=bool(g["lightattn"]))
+    sd = weights.synthetic_state_dict(int(g["weight_seed"]), head=head)
+
+    class AD(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+    os.makedirs(tmp_path / "vanilla_model_weights")
+    weights.save_vanilla_checkpoint(tmp_path / "vanilla_model_weights" / "v_48_020.pt", weights.split_transfer_state_dict(sd)[0], 48)
+    cfg = AD(model=AD(subtract_mut=True, freeze_weights=True, load_pretrained=True, **head), platform=AD(thermompnn_dir=str(tmp_path)))
+    model = TransferModel(cfg)
+    assert model.generic_head and not model.load_state_dict(sd).missing_keys
+    model = model.eval().cuda()
+    pdb = pdb_io.alt_parse_PDB(os.path.join(GOLDEN, "2OCJ.pdb"), "A")
+    muts = mutation_objects(pdb[0])
+    with torch.no_grad():
+        pred, _ = model(pdb, muts)
+    got = torch.cat([p["ddG"] for p in pred]).cpu().numpy().reshape(194, 20)
+    np.testing.assert_allclose(got, g["ddg"], atol=1e-4, rtol=0)
+    # the head table z itself, and a stated wild type that differs from the structure (uses z, not the ddG table)
+    eng = model.engine()
+    f = pdb_io.tied_featurize([pdb[0]], "cuda:0", None)
+    res = eng.ssm_forward(f[0][0], f[1][0], f[2][0], f[12][0], f[5][0], torch.tensor([0, 194], dtype=torch.int32), want_hidden=True, want_ddg=False)
+    _, z = model._generic_tables(eng, res["hidden"], f[1][0])
+    np.testing.assert_allclose(z.cpu().numpy(), g["z"], atol=1e-5, rtol=0)
+    from thermompnn_amd.datasets import Mutation
+    wt_other = "A" if pdb[0]["seq"][7] != "A" else "G"
+    with torch.no_grad():
+        p2, _ = model(pdb, [Mutation(7, wt_other, "W", None, "2OCJ")])
+    want = 1.7 * (g["z"][7, "ACDEFGHIKLMNPQRSTVWY".index("W")] - g["z"][7, "ACDEFGHIKLMNPQRSTVWY".index(wt_other)])
+    assert abs(p2[0]["ddG"].item() - want) <= 1e-4
+    # the engine refuses layouts that are not a TransferModel head
+    from thermompnn_amd._lib import TmpnnError
+    with pytest.raises(TmpnnError):
+        eng.ddg_head_generic([res["hidden"][2]], f[1][0], model.prot_mpnn.W_s.weight, [torch.zeros(21, 100)], [torch.zeros(21)],
+                             model.ddg_out.weight, model.ddg_out.bias)

@@ -50,6 +50,8 @@ SIGNATURES = {
     "tmpnn_seq_embed": (_i, [_p, _p, _i64, _p, _p]),
     "tmpnn_log_probs": (_i, [_p, _p, _i64, _p, _p, _p]),
     "tmpnn_ddg_head": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "tmpnn_head_generic_workspace_bytes": (_sz, [_i64, _i, _i, _p]),
+    "tmpnn_ddg_head_generic": (_i, [_p, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "tmpnn_pdb_parse": (_i, [C.c_char_p, C.c_char_p, C.POINTER(_p)]),
     "tmpnn_pdb_parse_batch": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _i, _i, C.POINTER(_p)]),
     "tmpnn_pdb_length": (_i64, [_p]),

@@ -573,6 +573,43 @@ extern "C" int tmpnn_ddg_head(const tmpnn_weights_t *w, const float *hV_last, co
     return launch_head(w, hV_last, hV_prev, S, T, ddg, z_opt, status_opt, (hipStream_t)stream);
 }
 
+// ---- generic head ----------------------------------------------------------------------------------
+static int head_generic_dims_ok(int n_final, int n_layers, const int32_t *dims) {
+    if (n_final < 0 || n_final > 3 || n_layers < 1 || n_layers > 8 || !dims) return 0;
+    if (dims[0] != TMPNN_HID * n_final + TMPNN_HID || dims[n_layers] != TMPNN_VOCAB) return 0;
+    for (int l = 1; l < n_layers; ++l)
+        if (dims[l] < 1 || dims[l] > 4096) return 0;
+    return 1;
+}
+
+extern "C" size_t tmpnn_head_generic_workspace_bytes(int64_t T, int n_final, int n_layers, const int32_t *dims) {
+    if (T < 0 || !head_generic_dims_ok(n_final, n_layers, dims)) return 0;
+    int widest = dims[0];
+    for (int l = 1; l <= n_layers; ++l) widest = dims[l] > widest ? dims[l] : widest;
+    return 2 * align256((size_t)T * widest * sizeof(float));
+}
+
+extern "C" int tmpnn_ddg_head_generic(const float *const *hidden, int n_final, const float *Ws, const int32_t *S, int64_t T,
+                                      const float *conv_w, const float *conv_b, int n_layers, const float *const *mlp_w,
+                                      const float *const *mlp_b, const int32_t *dims, const float *ddg_w, const float *ddg_b,
+                                      float *ddg, float *z_opt, void *workspace, size_t workspace_bytes, int32_t *status_opt,
+                                      tmpnn_stream_t stream) {
+    REQUIRE(head_generic_dims_ok(n_final, n_layers, dims),
+            "ddg_head_generic: dims must run from 128 * num_final_layers + 128 to 21 over 1..8 layers (num_final_layers 0..3)");
+    REQUIRE(Ws && S && mlp_w && mlp_b && ddg_w && ddg_b && ddg && (n_final == 0 || hidden), "ddg_head_generic: null pointer");
+    for (int i = 0; i < n_final; ++i) REQUIRE(hidden[i], "ddg_head_generic: hidden[%d] is null", i);
+    for (int l = 0; l < n_layers; ++l) REQUIRE(mlp_w[l] && mlp_b[l], "ddg_head_generic: layer %d has a null weight / bias", l);
+    REQUIRE((conv_w == nullptr) == (conv_b == nullptr), "ddg_head_generic: conv weight and bias go together");
+    REQUIRE(T >= 0 && T <= T_MAX, "ddg_head_generic: bad T");
+    if (T == 0) return TMPNN_OK;
+    const size_t need = tmpnn_head_generic_workspace_bytes(T, n_final, n_layers, dims);
+    if (!workspace || workspace_bytes < need)
+        return tm_set_error(TMPNN_E_WORKSPACE, "ddg_head_generic: workspace %zu < %zu bytes", workspace_bytes, need);
+    float *buf0 = (float *)workspace, *buf1 = (float *)((char *)workspace + need / 2);
+    return launch_head_generic(hidden, n_final, Ws, S, T, conv_w, conv_b, n_layers, mlp_w, mlp_b, dims, ddg_w, ddg_b, ddg, z_opt,
+                               buf0, buf1, status_opt, (hipStream_t)stream);
+}
+
 extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const int32_t *S, const float *mask,
                                  const int32_t *residue_idx, const int32_t *chain_enc, const int32_t *offsets,
                                  int n_proteins, int64_t T, int max_len, int K, float *ddg, float *hidden_opt,

@@ -476,3 +476,112 @@ int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float 
     { tm_prof_begin("seq_embed", st); seq_embed_kernel<<<(int)(blocks < cap ? blocks : cap), TM_THREADS, 0, st>>>(w->Ws_w, S, T, hS); tm_prof_end(st); }
     return tm_check_launch("seq_embed");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Generic head: any TransferModel configuration the reference constructor accepts (transfer_model.py:45-73) —
+// num_final_layers 0..3 decoder states in the input, LightAttention on or off (:106-108), any list of hidden_dims.
+// The released configuration (2 states, LightAttention, [64, 32]) runs head8_split_kernel above; this path keeps retrained
+// heads runnable: x = [h_dec(last) | ... | W_s[S]] -> (centre tap of feature_convolution) -> [ReLU, Linear] x n -> ddG.
+// One dense kernel on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, weights as the A operand so a lane ends up with four
+// consecutive output columns of one row), operands straight from global memory: sized for correctness and generality.
+// ------------------------------------------------------------------------------------------------
+struct ConcatArgs { const float *hid[3]; int n_final; const float *Ws; const int32_t *S; float *X; int T, D0; int32_t *status; };
+
+__global__ __launch_bounds__(TM_THREADS) void head_concat_kernel(ConcatArgs a) {
+    const int per_row = a.D0 / 4;
+    bool bad = false;
+    for (int64_t e = (int64_t)tm_bid() * TM_THREADS + tm_tid(); e < (int64_t)a.T * per_row; e += (int64_t)tm_nblk() * TM_THREADS) {
+        const int t = (int)(e / per_row), c = (int)(e - (int64_t)t * per_row), blk = c / 32, c4 = c - blk * 32;
+        typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+        uv4 v;
+        if (blk < a.n_final) {
+            v = *reinterpret_cast<const uv4 *>(a.hid[blk] + (size_t)t * TM_H + 4 * c4);
+            // the ReLU in front of the first Linear maps NaN to 0: a poisoned decoder state is flagged here, on the raw bits
+            bad = bad || tm_nonfinite_bits(v.x) || tm_nonfinite_bits(v.y) || tm_nonfinite_bits(v.z) || tm_nonfinite_bits(v.w);
+        } else {
+            v = *reinterpret_cast<const uv4 *>(a.Ws + (size_t)a.S[t] * TM_H + 4 * c4);
+        }
+        *reinterpret_cast<uv4 *>(a.X + (size_t)t * a.D0 + 4 * c) = v;
+    }
+    if (bad && a.status) atomicOr(a.status, TMPNN_STATUS_RANGE);
+}
+
+// Y[t, n] = b[n] + sum_k act(X[t, k]) W[n, k]; W element (n, k) at W[n * ldw + wk0 + k * wks] (a Linear: wks 1; the centre tap of a
+// [N, K, 9] convolution weight: ldw 9 K, wks 9, wk0 4). One wavefront per 16-row tile, all column blocks in turn.
+struct DenseArgs { const float *X; const float *W; const float *b; float *Y; int T, K, N, ldw, wks, wk0, relu_in; };
+
+__global__ __launch_bounds__(TM_THREADS) void dense_generic_kernel(DenseArgs a) {
+    const int lane = tm_tid() & 63, wv = tm_wave(tm_tid()), m = lane & 15, q = lane >> 4;
+    const int n_tiles = (a.T + 15) / 16;
+    for (int tile = tm_bid() * 4 + wv; tile < n_tiles; tile += tm_nblk() * 4) {
+        const int row = tile * 16 + m;
+        const bool row_ok = row < a.T;
+        const float *x = a.X + (size_t)(row_ok ? row : 0) * a.K;
+        for (int n0 = 0; n0 < a.N; n0 += 16) {
+            const int wrow = n0 + m;
+            const bool w_ok = wrow < a.N;
+            const float *w = a.W + (size_t)(w_ok ? wrow : 0) * a.ldw + a.wk0;
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < a.K; k += 4) {
+                const int kk = k + q;
+                const bool k_ok = kk < a.K;
+                float xv = row_ok && k_ok ? x[kk] : 0.f;
+                if (a.relu_in) xv = fmaxf(xv, 0.f);
+                const float wvv = w_ok && k_ok ? w[(size_t)kk * a.wks] : 0.f;
+                acc = mfma16(wvv, xv, acc);
+            }
+            if (row_ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = n0 + 4 * q + r;
+                    if (col < a.N) a.Y[(size_t)row * a.N + col] = acc[r] + a.b[col];
+                }
+            }
+        }
+    }
+}
+
+// ddg[t, a] = (w z[t, a] + b) - (w z[t, S[t]] + b) (:110-116; subtract_mut) — or w z + b alone; column 20 ('X') included like the
+// fused head's table.
+__global__ __launch_bounds__(TM_THREADS) void ddg_from_z_kernel(const float *__restrict__ z, const int32_t *__restrict__ S,
+                                                                const float *__restrict__ dwp, const float *__restrict__ dbp, int T,
+                                                                float *__restrict__ ddg, int32_t *__restrict__ status) {
+    const float dw = dwp[0], db = dbp[0];
+    for (int64_t e = (int64_t)tm_bid() * TM_THREADS + tm_tid(); e < (int64_t)T * TMPNN_VOCAB; e += (int64_t)tm_nblk() * TM_THREADS) {
+        const int t = (int)(e / TMPNN_VOCAB);
+        const float dd = (dw * z[e] + db) - (dw * z[(size_t)t * TMPNN_VOCAB + S[t]] + db);
+        ddg[e] = dd;
+        if (status && tm_nonfinite(dd)) atomicOr(status, TMPNN_STATUS_RANGE);
+    }
+}
+
+int launch_head_generic(const float *const *hidden, int n_final, const float *Ws, const int32_t *S, int64_t T, const float *conv_w,
+                        const float *conv_b, int n_layers, const float *const *mlp_w, const float *const *mlp_b, const int32_t *dims,
+                        const float *ddg_w, const float *ddg_b, float *ddg, float *z_opt, float *buf0, float *buf1, int32_t *status,
+                        hipStream_t st) {
+    const int D0 = dims[0];
+    const int64_t cap = (int64_t)tm_num_cus() * 8;
+    auto grid_for = [&](int64_t work_items) { const int64_t b = (work_items + TM_THREADS - 1) / TM_THREADS; return (int)(b < cap ? (b > 0 ? b : 1) : cap); };
+    ConcatArgs c{{n_final > 0 ? hidden[0] : nullptr, n_final > 1 ? hidden[1] : nullptr, n_final > 2 ? hidden[2] : nullptr}, n_final, Ws, S, buf0,
+                 (int)T, D0, status};
+    tm_prof_begin("head", st);
+    head_concat_kernel<<<grid_for(T * (D0 / 4)), TM_THREADS, 0, st>>>(c);
+    float *cur = buf0, *nxt = buf1;
+    const int64_t tiles = (T + 15) / 16;
+    const int dgrid = (int)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap);
+    if (conv_w) {       // LightAttention on a length-1 sequence = the centre tap (index 4 of 9) of feature_convolution + its bias
+        DenseArgs d{cur, conv_w, conv_b, nxt, (int)T, D0, D0, 9 * D0, 9, 4, 0};
+        dense_generic_kernel<<<dgrid, TM_THREADS, 0, st>>>(d);
+        std::swap(cur, nxt);
+    }
+    for (int l = 0; l < n_layers; ++l) {
+        const bool last = l == n_layers - 1;
+        float *out = last && z_opt ? z_opt : nxt;
+        DenseArgs d{cur, mlp_w[l], mlp_b[l], out, (int)T, dims[l], dims[l + 1], dims[l], 1, 0, 1};     // both_out: ReLU FIRST (:69-71)
+        dense_generic_kernel<<<dgrid, TM_THREADS, 0, st>>>(d);
+        if (out == nxt) std::swap(cur, nxt); else cur = out;
+    }
+    ddg_from_z_kernel<<<grid_for(T * TMPNN_VOCAB), TM_THREADS, 0, st>>>(cur, S, ddg_w, ddg_b, (int)T, ddg, status);
+    tm_prof_end(st);
+    return tm_check_launch("ddg_head_generic");
+}

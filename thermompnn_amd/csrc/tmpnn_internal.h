@@ -101,6 +101,10 @@ int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const 
 int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, int32_t *status, hipStream_t st,
                      const int32_t *maxlen_probe = nullptr);
 int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float *hS, hipStream_t st);
+int launch_head_generic(const float *const *hidden, int n_final, const float *Ws, const int32_t *S, int64_t T, const float *conv_w,
+                        const float *conv_b, int n_layers, const float *const *mlp_w, const float *const *mlp_b, const int32_t *dims,
+                        const float *ddg_w, const float *ddg_b, float *ddg, float *z_opt, float *buf0, float *buf1, int32_t *status,
+                        hipStream_t st);
 int launch_range_check(const float *x, int64_t n, int32_t *status, hipStream_t st, const int32_t *maxlen_probe = nullptr,
                        int64_t T = 0);   // ORs TMPNN_STATUS_RANGE if any x is inf / NaN (+ the MAXLEN probe of the fused forward)
 int launch_prep_tables(tmpnn_weights *w, hipStream_t st);

@@ -99,12 +99,12 @@ class Engine:
     """One weight set on one GPU. All tensors are packed along the residue axis (T = sum of lengths)."""
 
     def __init__(self, state_dict, device="cuda", k_neighbors: int = 48, precision: Optional[str] = None,
-                 retry_precision: Optional[str] = "bf16x3"):
+                 retry_precision: Optional[str] = "bf16x3", with_head: Optional[bool] = None):
         """``precision``: matrix-core path of the per-edge GEMMs ("f16x2" default | "bf16x3" | "fp32").
         ``retry_precision``: when a forward in f16x2 leaves the finite range (an operand >= 65504 overflowed fp16), it is
         rerun once at this precision with a warning (None: raise TmpnnRangeError instead)."""
         self.lib = _lib.load()
-        self.w = Weights(state_dict, device, precision=precision)
+        self.w = Weights(state_dict, device, with_head=with_head, precision=precision)
         self.device = self.w.device
         self.precision = self.w.precision
         self.retry_precision = retry_precision
@@ -221,6 +221,43 @@ class Engine:
         z = torch.empty_like(ddg) if want_z else None
         check(self.lib.tmpnn_ddg_head(self.w.handle, _ptr(hV_last), _ptr(hV_prev), _ptr(S), T, _ptr(ddg), _ptr(z),
                                       None, _stream()), "tmpnn_ddg_head")
+        return (ddg, z) if want_z else ddg
+
+    def ddg_head_generic(self, hidden: Sequence[torch.Tensor], S, Ws: torch.Tensor, mlp_w: Sequence[torch.Tensor],
+                         mlp_b: Sequence[torch.Tensor], ddg_w: torch.Tensor, ddg_b: torch.Tensor,
+                         conv_w: Optional[torch.Tensor] = None, conv_b: Optional[torch.Tensor] = None, want_z: bool = False):
+        """The head of ANY TransferModel configuration (tmpnn_ddg_head_generic): ``hidden`` = the decoder states that enter the
+        input, LAST layer first (all_mpnn_hid[:num_final_layers], transfer_model.py:84-85); ``conv_w`` [D0, D0, 9] / ``conv_b``
+        = LightAttention's feature convolution or None; ``mlp_w[l]`` / ``mlp_b[l]`` = both_out's Linear l. -> ddg [T,21] (, z)."""
+        S = self._i32(S)
+        T = S.numel()
+        f = lambda t: None if t is None else t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        hidden = [f(h) for h in hidden]
+        mlp_w, mlp_b = [f(w) for w in mlp_w], [f(b) for b in mlp_b]
+        Ws, ddg_w, ddg_b, conv_w, conv_b = f(Ws), f(ddg_w), f(ddg_b), f(conv_w), f(conv_b)
+        _need_cuda(S, Ws, *hidden)
+        n_layers = len(mlp_w)
+        dims = [HID * len(hidden) + HID] + [int(w.shape[0]) for w in mlp_w]
+        for l, w in enumerate(mlp_w):
+            if tuple(w.shape) != (dims[l + 1], dims[l]) or mlp_b[l].numel() != dims[l + 1]:
+                raise TmpnnError(f"both_out Linear {l}: weight {tuple(w.shape)}, expected {(dims[l + 1], dims[l])}")
+        if conv_w is not None and tuple(conv_w.shape) != (dims[0], dims[0], 9):
+            raise TmpnnError(f"feature_convolution weight {tuple(conv_w.shape)}, expected {(dims[0], dims[0], 9)}")
+        cdims = (C.c_int32 * len(dims))(*dims)
+        arr = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
+        need = self.lib.tmpnn_head_generic_workspace_bytes(T, len(hidden), n_layers, cdims)
+        if T > 0 and need == 0:
+            raise TmpnnError(f"head dims {dims} (num_final_layers {len(hidden)}): not a TransferModel head layout")
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+        ddg = torch.empty((T, VOCAB), dtype=torch.float32, device=self.device)
+        z = torch.empty_like(ddg) if want_z else None
+        self._status.zero_()
+        check(self.lib.tmpnn_ddg_head_generic(arr(hidden), len(hidden), _ptr(Ws), _ptr(S), T, _ptr(conv_w), _ptr(conv_b), n_layers,
+                                              arr(mlp_w), arr(mlp_b), cdims, _ptr(ddg_w), _ptr(ddg_b), _ptr(ddg), _ptr(z), _ptr(ws),
+                                              ws.numel(), _ptr(self._status), _stream()), "tmpnn_ddg_head_generic")
+        st = self._raise_status("tmpnn_ddg_head_generic")
+        if st:
+            check(self.lib.tmpnn_status_error(st), "tmpnn_ddg_head_generic")
         return (ddg, z) if want_z else ddg
 
     def gather_rows(self, nodes, idx_i32):

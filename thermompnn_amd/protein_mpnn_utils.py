@@ -41,6 +41,7 @@ class _EngineOwner(nn.Module):
     k_neighbors = 48
     precision = None          # matrix-core path of the engine ("f16x2" | "bf16x3" | "fp32"; None = library default)
     retry_precision = "bf16x3"   # Engine reruns an f16x2 forward that left the fp16 range at this precision (None: raise)
+    _engine_kwargs: dict = {}    # extra Engine(...) arguments of a subclass (TransferModel with a generic head: with_head=False)
 
     def _state_for_engine(self):
         return {k: v for k, v in self.state_dict().items()}
@@ -54,7 +55,7 @@ class _EngineOwner(nn.Module):
         key = (tuple((p.data_ptr(), p._version) for p in params), self.precision, self.retry_precision)
         if self._engine is None or key != self._engine_key:
             self._engine = Engine(self._state_for_engine(), dev, self.k_neighbors, precision=self.precision,
-                                  retry_precision=self.retry_precision)
+                                  retry_precision=self.retry_precision, **self._engine_kwargs)
             self._engine_key = key
         return self._engine
 

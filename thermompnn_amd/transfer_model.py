@@ -55,14 +55,31 @@ class TransferModel(_EngineOwner):
         self.lightattn = _cfg_get(cfg.model, "lightattn", False)
         if "decoding_order" not in self.cfg:                      # the reference writes this back (:50-51)
             self.cfg.decoding_order = "left-to-right"
-        if self.hidden_dims != [64, 32] or self.num_final_layers != 2 or not self.lightattn:
-            raise NotImplementedError("the HIP head is specialised for the released ThermoMPNN configuration "
-                                      "(hidden_dims [64, 32], num_final_layers 2, lightattn true; config.yaml:15-21)")
+        if not 0 <= int(self.num_final_layers) <= 3:
+            raise ValueError(f"num_final_layers={self.num_final_layers}: ProteinMPNN has 3 decoder states (transfer_model.py:84-85)")
+        # the released configuration (config.yaml:15-21) runs the specialised fused head; any other one the reference
+        # constructor accepts (:45-73) runs the generic head kernels (tmpnn_ddg_head_generic) behind the same forward
+        self.generic_head = self.hidden_dims != [64, 32] or int(self.num_final_layers) != 2 or not self.lightattn
+        self._engine_kwargs = {"with_head": False} if self.generic_head else {}   # generic head: the handle holds the 118 ProteinMPNN tensors
         self.prot_mpnn = get_protein_mpnn(cfg)
         self.k_neighbors = self.prot_mpnn.k_neighbors
-        _register_tree(self, _weights.head_param_shapes(self.hidden_dims))
+        _register_tree(self, _weights.head_param_shapes(self.hidden_dims, int(self.num_final_layers), bool(self.lightattn)))
         with torch.no_grad():                                      # nn.Linear(1, 1)-like non-degenerate default
             self.ddg_out.weight.fill_(1.0)
+
+    def _state_for_engine(self):
+        sd = self.state_dict()
+        return {k: v for k, v in sd.items() if k.startswith("prot_mpnn.")} if self.generic_head else dict(sd)
+
+    def _generic_tables(self, eng, hidden, S):
+        """(ddG table [L,21], z [L,21]) through tmpnn_ddg_head_generic for a non-default head configuration."""
+        n = int(self.num_final_layers)
+        layers = [getattr(self.both_out, str(2 * i + 1)) for i in range(len(self.hidden_dims) + 1)]
+        conv = self.light_attention.feature_convolution if self.lightattn else None
+        return eng.ddg_head_generic([hidden[2 - k] for k in range(n)], S, self.prot_mpnn.W_s.weight, [l.weight for l in layers],
+                                    [l.bias for l in layers], self.ddg_out.weight, self.ddg_out.bias,
+                                    conv_w=None if conv is None else conv.weight, conv_b=None if conv is None else conv.bias,
+                                    want_z=True)
 
     def forward(self, pdb, mutations, tied_feat=True):
         device = next(self.parameters()).device
@@ -72,7 +89,11 @@ class TransferModel(_EngineOwner):
         L = X.shape[1]
         with torch.cuda.device(eng.device):
             res = eng.ssm_forward(X[0], S[0], mask[0], residue_idx[0], chain_enc[0],
-                                  torch.tensor([0, L], dtype=torch.int32), max_len=L, want_hidden=True)
+                                  torch.tensor([0, L], dtype=torch.int32), max_len=L, want_hidden=True,
+                                  want_ddg=not self.generic_head)
+            z_generic = None
+            if self.generic_head:
+                res["ddg"], z_generic = self._generic_tables(eng, res["hidden"], S[0])
             ddg = res["ddg"]                                        # [L,21]: (w z_a + b) - (w z_wt + b), wt = S
             pos, aa, wt = [], [], []
             for m in mutations:
@@ -89,7 +110,7 @@ class TransferModel(_EngineOwner):
                 vals = ddg[pos_t, aa_t]
             else:   # a stated wild type that differs from the structure, or subtract_mut=False: use z directly
                 hid = res["hidden"]
-                _, z = eng.ddg_head(hid[2], hid[1], S[0], want_z=True)
+                z = z_generic if self.generic_head else eng.ddg_head(hid[2], hid[1], S[0], want_z=True)[1]
                 zz = z * self.ddg_out.weight.view(()) + self.ddg_out.bias.view(())
                 vals = zz[pos_t, aa_t] - zz[pos_t, wt_t] if self.subtract_mut else zz[pos_t, aa_t]
         out, k = [], 0

@@ -65,13 +65,16 @@ def mpnn_param_shapes(num_enc: int = 3, num_dec: int = 3) -> "OrderedDict[str, t
     return s
 
 
-def head_param_shapes(hidden_dims=(64, 32)) -> "OrderedDict[str, tuple]":
-    """TransferModel's own parameters (transfer_model.py:57-73, 131-134)."""
+def head_param_shapes(hidden_dims=(64, 32), num_final_layers: int = 2, lightattn: bool = True) -> "OrderedDict[str, tuple]":
+    """TransferModel's own parameters (transfer_model.py:57-73, 131-134) for any configuration its constructor accepts:
+    input width 128 * num_final_layers + 128, LightAttention's two convolutions only when ``lightattn``."""
     s: "OrderedDict[str, tuple]" = OrderedDict()
-    for conv in ("feature_convolution", "attention_convolution"):
-        s[f"light_attention.{conv}.weight"] = (HEAD_IN, HEAD_IN, 9)
-        s[f"light_attention.{conv}.bias"] = (HEAD_IN,)
-    sizes = [HEAD_IN, *hidden_dims, VOCAB]
+    head_in = H * int(num_final_layers) + H
+    if lightattn:
+        for conv in ("feature_convolution", "attention_convolution"):
+            s[f"light_attention.{conv}.weight"] = (head_in, head_in, 9)
+            s[f"light_attention.{conv}.bias"] = (head_in,)
+    sizes = [head_in, *hidden_dims, VOCAB]
     for i, (a, b) in enumerate(zip(sizes, sizes[1:])):
         s[f"both_out.{2 * i + 1}.weight"] = (b, a)   # ReLU sits at even indices
         s[f"both_out.{2 * i + 1}.bias"] = (b,)
@@ -80,11 +83,11 @@ def head_param_shapes(hidden_dims=(64, 32)) -> "OrderedDict[str, tuple]":
     return s
 
 
-def transfer_param_shapes() -> "OrderedDict[str, tuple]":
+def transfer_param_shapes(hidden_dims=(64, 32), num_final_layers: int = 2, lightattn: bool = True) -> "OrderedDict[str, tuple]":
     s: "OrderedDict[str, tuple]" = OrderedDict()
     for k, v in mpnn_param_shapes().items():
         s["prot_mpnn." + k] = v
-    s.update(head_param_shapes())
+    s.update(head_param_shapes(hidden_dims, num_final_layers, lightattn))
     return s
 
 
@@ -115,12 +118,14 @@ def _draw(rng: np.random.Generator, name: str, shape: tuple, style: str = "xavie
     return rng.uniform(-bound, bound, shape).astype(np.float32)
 
 
-def synthetic_state_dict(seed: int = 0, which: str = "transfer", style: str = "xavier") -> "OrderedDict[str, torch.Tensor]":
-    """Deterministic synthetic weights. ``which`` = 'transfer' (full TransferModel tree) or 'mpnn'; ``style`` see _draw."""
+def synthetic_state_dict(seed: int = 0, which: str = "transfer", style: str = "xavier", head=None) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic synthetic weights. ``which`` = 'transfer' (full TransferModel tree) or 'mpnn'; ``style`` see _draw;
+    ``head`` = dict(hidden_dims=..., num_final_layers=..., lightattn=...) for a non-default TransferModel head (the ProteinMPNN
+    tensors come first, so they are the same draws whatever the head)."""
     if style not in STYLES:
         raise ValueError(f"style={style!r}: expected one of {STYLES}")
     rng = np.random.default_rng(seed)
-    shapes = transfer_param_shapes() if which == "transfer" else mpnn_param_shapes()
+    shapes = transfer_param_shapes(**(head or {})) if which == "transfer" else mpnn_param_shapes()
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for name, shape in shapes.items():
         out[name] = torch.from_numpy(_draw(rng, name, shape, style))
