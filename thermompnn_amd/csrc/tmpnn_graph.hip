@@ -581,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
     static_assert(SP::NP * PLB >= TILEB, "the GEMM-2 planes are aliased on the RBF planes");
     __shared__ __attribute__((aligned(16))) char rbf[SP::NP * PLB];
     __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];   // fp32 output tile
-    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
+    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT8_LD];
     __shared__ float s_atoms[TM_TILE][16];
     __shared__ float s_self[16];
     __shared__ float s_dist[TM_TILE][28];

@@ -315,8 +315,13 @@ __device__ __forceinline__ void row_stats_partial1b(const f4 v, float *stat_slot
         mean = 0.5f * (ma + mb);
         m2 = __uint_as_float(p2[0]) + __uint_as_float(p2[1]) + delta * delta * 4.0f;
     }
-    if (q == 0) { stat_slot[0] = mean; stat_slot[1] = m2; }
+    if (q == 0) *reinterpret_cast<f2 *>(stat_slot) = f2{mean, m2};      // one 8-byte write (stat_slot is 8-byte aligned: even column)
 }
+// Pitch of the statistics rows these two functions use: 20 floats, not 16. With 16 the 16 lanes of a q = 0 group wrote to two bank
+// pairs (8-way conflict) and the 16-byte reads of finish8b below hit every fourth row on the same banks (4-way): the featurizer's
+// SQ_LDS_BANK_CONFLICT was 24 % of its LDS cycles (profiles/r03_pmc_sq_summary.txt). 20 keeps the rows 16-byte aligned, makes the
+// reads conflict-free (chunk 5 m + k mod 16 is a bijection in m) and leaves the writes 2-way.
+#define TM_STAT8_LD 20
 __device__ __forceinline__ void row_stats_finish8b(const float *stat_row, float &mean, float &rstd) {
     f4 p[4];
 #pragma unroll

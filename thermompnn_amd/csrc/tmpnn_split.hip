@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_split_kernel(EdgeArgsB a) {
     __shared__ __attribute__((aligned(16))) char tX[TILEB];              // x planes; later the fp32 LayerNorm input
     __shared__ __attribute__((aligned(16))) char tY[TILEB];
     __shared__ __attribute__((aligned(16))) float tStageB[NST][TM_TILE * TM_H]; // fp32 tiles landed by LDS-DMA
-    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][16];
+    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT8_LD];
     __shared__ int s_idx[2][TM_TILE];
     float *tO = reinterpret_cast<float *>(tX);
     const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
