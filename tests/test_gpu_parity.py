@@ -663,6 +663,9 @@ def test_small_launch_kernel_forms_are_bit_identical():
     r = subprocess.run([sys.executable, os.path.join(repo, "tools", "dbg_deep.py")], cwd=repo, capture_output=True, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if "max diff" in l]
     assert r.returncode == 0 and len(lines) == 3 and all("n diff 0 " in l for l in lines), r.stdout[-1500:] + r.stderr[-1500:]
+    # launches with at most one tile per workgroup fuse the edge update with the next message pass (edge_msg_fused_kernel)
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "dbg_fused.py")], cwd=repo, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL IDENTICAL" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
 def test_f16x2_range_limit_is_loud():

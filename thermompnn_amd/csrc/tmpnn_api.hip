@@ -647,13 +647,43 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     // (28 when every projection and the zero state are launches of their own)
     TRY(launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, nullptr, st, KnnInit{hV[0], ws.P, w->enc[0].b1, status_opt}));
     TRY(launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, hE, nullptr, st));
-    for (int l = 0; l < 3; ++l) {
-        const NodeProj next = l < 2 ? enc_msg_proj(w, l + 1, ws.P) : dec_msg_proj(w, 0, ws.P, S);
-        TRY(run_enc_layer(w, l, hV[0], hE, E_idx, mask, T, ws, true, &next, st));
-    }
-    for (int l = 0; l < 3; ++l) {
-        const NodeProj next = dec_msg_proj(w, l < 2 ? l + 1 : 2, ws.P, S);
-        TRY(run_dec_layer(w, l, hV[l], hV[l + 1], hE, E_idx, S, mask, T, ws, true, l < 2 ? &next : nullptr, st));
+    static const bool fuse_small = TM_DBG_FLAG("TMPNN_FUSE_SMALL", true);     // (A/B switch in the debug library only)
+    if (fuse_small && edge_msg_fusable(tm_matmul_mode(), T)) {
+        // One tile per workgroup (a single protein, a few short ones): the edge update of encoder layer l and the message pass of
+        // the layer after it are ONE launch (edge_msg_fused_kernel: no grid-wide dependency between them; 16 launches instead
+        // of 19, bit-identical results). Launch order: msg0, node0, [edge0 + msg1], node1, [edge1 + msg2], node2,
+        // [edge2 + dec msg0], dnode0, dmsg1, dnode1, dmsg2, dnode2.
+        for (int l = 0; l < 3; ++l) {
+            const EncW &e = w->enc[l];
+            if (l == 0) TRY(launch_msg(false, e.W1 + 128, 384, e.W2, e.b2, ws.P, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
+            const NodeProj next = l < 2 ? enc_msg_proj(w, l + 1, ws.P) : dec_msg_proj(w, 0, ws.P, S);
+            const NodeProj ep{e.W11, 384, e.b11, e.W11 + 256, 384, ws.P2, nullptr, nullptr};
+            TRY(launch_node_update(e.W3, e.b3, e.norm1_w, e.norm1_b, e.Win, e.bin, e.Wout, e.bout, e.norm2_w, e.norm2_b, hV[0],
+                                   ws.Ssum, ws.cnt, mask, T, hV[0], &ep, &next, st));
+            if (l < 2) {
+                const EncW &n = w->enc[l + 1];
+                TRY(launch_edge_msg_fused(e, ws.P2, hE, E_idx, false, n.W1 + 128, 384, n.W2, n.b2, ws.P, mask, T, ws.Ssum, ws.cnt, st));
+            } else {
+                const DecW &d = w->dec[0];
+                TRY(launch_edge_msg_fused(e, ws.P2, hE, E_idx, true, d.W1 + 128, 512, d.W2, d.b2, ws.P, mask, T, ws.Ssum, ws.cnt, st));
+            }
+        }
+        for (int l = 0; l < 3; ++l) {
+            const DecW &d = w->dec[l];
+            if (l > 0) TRY(launch_msg(true, d.W1 + 128, 512, d.W2, d.b2, ws.P, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
+            const NodeProj next = dec_msg_proj(w, l < 2 ? l + 1 : 2, ws.P, S);
+            TRY(launch_node_update(d.W3, d.b3, d.norm1_w, d.norm1_b, d.Win, d.bin, d.Wout, d.bout, d.norm2_w, d.norm2_b, hV[l],
+                                   ws.Ssum, ws.cnt, mask, T, hV[l + 1], l < 2 ? &next : nullptr, nullptr, st));
+        }
+    } else {
+        for (int l = 0; l < 3; ++l) {
+            const NodeProj next = l < 2 ? enc_msg_proj(w, l + 1, ws.P) : dec_msg_proj(w, 0, ws.P, S);
+            TRY(run_enc_layer(w, l, hV[0], hE, E_idx, mask, T, ws, true, &next, st));
+        }
+        for (int l = 0; l < 3; ++l) {
+            const NodeProj next = dec_msg_proj(w, l < 2 ? l + 1 : 2, ws.P, S);
+            TRY(run_dec_layer(w, l, hV[l], hV[l + 1], hE, E_idx, S, mask, T, ws, true, l < 2 ? &next : nullptr, st));
+        }
     }
     if (ddg) TRY(launch_head(w, hV[3], hV[2], S, T, ddg, nullptr, status_opt, st, E_idx));
     if (log_probs_opt) TRY(launch_log_probs(w, hV[3], T, log_probs_opt, status_opt, st, ddg ? nullptr : E_idx));

@@ -115,6 +115,11 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                      const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt, hipStream_t st);
 int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t T, int reps, hipStream_t st);
+// small launches (one tile per workgroup): edge update of layer l + message pass of the next layer as one launch (bit-identical)
+bool edge_msg_fusable(int mode, int64_t T);
+int launch_edge_msg_fused(const EncW &e, const float *P_edge, float *hE, const int32_t *E_idx, bool dec, const float *W1e, int ld1,
+                          const float *W2, const float *b2, const float *P_msg, const float *mask, int64_t T, float *Ssum, float *cnt,
+                          hipStream_t st);
 int launch_selftest(int32_t *status, hipStream_t st);
 
 int tm_num_cus();
