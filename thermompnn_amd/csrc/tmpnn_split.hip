@@ -842,6 +842,10 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
     for (int i = tm_bid(); i < a.T; i += tm_nblk()) {
         // ---- edge update of this tile (enc_edge8_rp_kernel) ------------------------------------------
         f4 e_cur[3], yrow[3];
+        f4 g0, gj[3];                                    // the message pass's node terms: requested with the edge update's (same list)
+        float mi, nma = 0.f;
+        WFragS<SP> w1[1][4], w2[1][4];                   // the message weights: requested when the edge weights are dead (behind GEMM 3)
+        f4 bias2;
         {
             WFragS<SP> w11[1][4], w12[1][4], w13[1][4];
             load_wfrag_auto<SP>(a.img11, a.W11e, 384, wv, lane, w11[0]);
@@ -861,6 +865,17 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             for (int rb = 0; rb < 3; ++rb) {
                 const int j = s_idx[16 * rb + m];
                 gcj[rb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol);
+            }
+            g0 = ld4(b.P + (size_t)i * 256 + ucol);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                const int j0 = s_idx[16 * rb + m];
+                gj[rb] = ld4(b.P + (size_t)(j0 < 0 ? i : j0) * 256 + 128 + ncol);
+            }
+            mi = b.mask[i];
+            if (tid < TM_TILE) {
+                const int j = s_idx[tid];
+                nma = j < 0 ? 0.f : (DEC ? 1.f : b.mask[i] * b.mask[j]);
             }
             __syncthreads();
             f4 acc[3][1];
@@ -897,6 +912,9 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
                 st4(tO + chunk_off(16 * rb + m, c4), v);
                 row_stats_partial16(v, &s_stat[16 * rb + m][2 * wv], q);
             }
+            load_wfrag_auto<SP>(b.img1, b.W1e, b.ld1, wv, lane, w1[0]);          // under the LayerNorm / store phase below
+            load_wfrag_auto<SP>(b.img2, b.W2, TM_H, wv, lane, w2[0]);
+            bias2 = ld4(b.b2 + ncol);
             __syncthreads();                                                     // tE free, tO + stats complete
 #pragma unroll
             for (int it = 0; it < 3; ++it) {
@@ -915,25 +933,10 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
         }
         // ---- message pass of the next layer on the SAME tile (msg8_rp_kernel) ------------------------------
         {
-            WFragS<SP> w1[1][4], w2[1][4];
-            load_wfrag_auto<SP>(b.img1, b.W1e, b.ld1, wv, lane, w1[0]);
-            load_wfrag_auto<SP>(b.img2, b.W2, TM_H, wv, lane, w2[0]);
-            const f4 bias2 = ld4(b.b2 + ncol);
-            const float mi = b.mask[i];
-            if (tid < TM_TILE) {
-                const int j = s_idx[tid];
-                s_ma[tid] = j < 0 ? 0.f : (DEC ? 1.f : b.mask[i] * b.mask[j]);
-            }
+            if (tid < TM_TILE) s_ma[tid] = nma;
             const int prow = 6 * wv + (lane >> 5), pc = lane & 31;              // the row layout the tile was just produced in
 #pragma unroll
             for (int it = 0; it < 3; ++it) store_split<SP>(tE, prow + 2 * it, pc, yrow[it]);
-            const f4 g0 = ld4(b.P + (size_t)i * 256 + ucol);
-            f4 gj[3];
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) {
-                const int j0 = s_idx[16 * rb + m];
-                gj[rb] = ld4(b.P + (size_t)(j0 < 0 ? i : j0) * 256 + 128 + ncol);
-            }
             __syncthreads();                                                     // e planes + s_ma complete; tO (= tA) consumed
             f4 acc[3][1];
 #pragma unroll
