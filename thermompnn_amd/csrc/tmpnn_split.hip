@@ -844,13 +844,15 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
         f4 e_cur[3], yrow[3];
         f4 g0, gj[3];                                    // the message pass's node terms: requested with the edge update's (same list)
         float mi, nma = 0.f;
-        WFragS<SP> w1[1][4], w2[1][4];                   // the message weights: requested when the edge weights are dead (behind GEMM 3)
+        // The five weight fragments are a software pipeline through TWO register sets (64 VGPRs), each requested one GEMM phase
+        // ahead of its use, into the set the previous GEMM has just finished with: fa = W11 -> W13 -> W2, fb = W12 -> W1.
+        // (All five resident, or the message pair requested early, spills — and a scratch reload's vmcnt wait drains every
+        //  prefetch in flight: 18.4 us per launch against 15.8.)
+        WFragS<SP> fa[1][4], fb[1][4];
         f4 bias2;
         {
-            WFragS<SP> w11[1][4], w12[1][4], w13[1][4];
-            load_wfrag_auto<SP>(a.img11, a.W11e, 384, wv, lane, w11[0]);
-            load_wfrag_auto<SP>(a.img12, a.W12, TM_H, wv, lane, w12[0]);
-            load_wfrag_auto<SP>(a.img13, a.W13, TM_H, wv, lane, w13[0]);
+            load_wfrag_auto<SP>(a.img11, a.W11e, 384, wv, lane, fa[0]);
+            load_wfrag_auto<SP>(a.img12, a.W12, TM_H, wv, lane, fb[0]);
             const f4 b12 = ld4(a.b12 + ncol), b13 = ld4(a.b13 + ncol);
             const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
             if (tid < TM_TILE) s_idx[tid] = a.E_idx[(size_t)i * TM_KS + tid];
@@ -873,15 +875,17 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
                 gj[rb] = ld4(b.P + (size_t)(j0 < 0 ? i : j0) * 256 + 128 + ncol);
             }
             mi = b.mask[i];
-            if (tid < TM_TILE) {
-                const int j = s_idx[tid];
-                nma = j < 0 ? 0.f : (DEC ? 1.f : b.mask[i] * b.mask[j]);
+            if (tid < TM_TILE) {                          // (only REQUESTED here; the product is formed in the message phase — a
+                const int j = s_idx[tid];                 //  use here would wait for every load above, in front of GEMM 1)
+                nma = b.mask[j < 0 ? i : j];
             }
             __syncthreads();
             f4 acc[3][1];
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
-            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tE, w11, acc, lane);
+            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tE, fa, acc, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            load_wfrag_auto<SP>(a.img13, a.W13, TM_H, wv, lane, fa[0]);          // W11 is done with: W13 for GEMM 3
             {
                 f4 g[3];
 #pragma unroll
@@ -893,7 +897,9 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             __syncthreads();
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
-            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tX, w12, acc, lane);
+            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tX, fb, acc, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            load_wfrag_auto<SP>(b.img1, b.W1e, b.ld1, wv, lane, fb[0]);          // W12 is done with: the message pass's W1
             {
                 f4 g[3];
 #pragma unroll
@@ -905,16 +911,16 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             __syncthreads();
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
-            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tY, w13, acc, lane);
+            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tY, fa, acc, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            load_wfrag_auto<SP>(b.img2, b.W2, TM_H, wv, lane, fa[0]);            // W13 is done with: the message pass's W2
+            bias2 = ld4(b.b2 + ncol);
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
                 const f4 v = e_cur[rb] + acc[rb][0];                             // residual on the fp32 tile
                 st4(tO + chunk_off(16 * rb + m, c4), v);
                 row_stats_partial16(v, &s_stat[16 * rb + m][2 * wv], q);
             }
-            load_wfrag_auto<SP>(b.img1, b.W1e, b.ld1, wv, lane, w1[0]);          // under the LayerNorm / store phase below
-            load_wfrag_auto<SP>(b.img2, b.W2, TM_H, wv, lane, w2[0]);
-            bias2 = ld4(b.b2 + ncol);
             __syncthreads();                                                     // tE free, tO + stats complete
 #pragma unroll
             for (int it = 0; it < 3; ++it) {
@@ -933,7 +939,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
         }
         // ---- message pass of the next layer on the SAME tile (msg8_rp_kernel) ------------------------------
         {
-            if (tid < TM_TILE) s_ma[tid] = nma;
+            if (tid < TM_TILE) s_ma[tid] = s_idx[tid] < 0 ? 0.f : (DEC ? 1.f : mi * nma);
             const int prow = 6 * wv + (lane >> 5), pc = lane & 31;              // the row layout the tile was just produced in
 #pragma unroll
             for (int it = 0; it < 3; ++it) store_split<SP>(tE, prow + 2 * it, pc, yrow[it]);
@@ -941,7 +947,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             f4 acc[3][1];
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
-            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tE, w1, acc, lane);
+            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tE, fb, acc, lane);
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
                 f4 v = acc[rb][0];
@@ -951,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             __syncthreads();
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = bias2;
-            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tX, w2, acc, lane);
+            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tX, fa, acc, lane);
             f4 tot = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
