@@ -2,7 +2,9 @@
 //   python -m thermompnn_amd.build --pdb-sanitizer-driver      (g++ -fsanitize=address,undefined -fno-sanitize-recover)
 // and fed malformed files by tests/test_host.py::test_native_parser_survives_malformed_input.
 // usage: pdb_fuzz_driver [--threads N] FILE...   -> one line per file: "<rc> <length> <chains> <checksum>"; any sanitizer
-// report aborts with a non-zero exit status. Parses every file alone, then all of them again through the threaded batch entry.
+// report aborts with a non-zero exit status. Parses every file alone, then all of them again through the threaded batch entry,
+// packs the batch into one ragged staging buffer (tmpnn_pdb_pack_batch) and runs the columnar CSV writer (tmpnn_csv.cpp: both
+// schemas, every post-processing flag, the listed-mutation form) over a synthetic table of the parsed structures.
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -51,8 +53,41 @@ int main(int argc, char **argv) {
     }
     std::vector<tmpnn_pdb_t *> hs(paths.size() + 1, nullptr);
     const int rc = tmpnn_pdb_parse_batch(paths.data(), nullptr, (int)paths.size(), threads, hs.data());
-    for (size_t i = 0; i < paths.size(); ++i)
-        if (hs[i]) { use(hs[i]); tmpnn_pdb_free(hs[i]); }
+    // a failing batch releases every handle; parse the survivors one by one for the pack / writer legs
+    std::vector<tmpnn_pdb_t *> ok;
+    std::vector<const char *> names;
+    if (rc != TMPNN_OK)
+        for (const char *p : paths) { tmpnn_pdb_t *h = nullptr; if (tmpnn_pdb_parse(p, nullptr, &h) == TMPNN_OK) { ok.push_back(h); names.push_back(p); } }
+    else
+        for (size_t i = 0; i < paths.size(); ++i) if (hs[i]) { use(hs[i]); ok.push_back(hs[i]); names.push_back(paths[i]); }
+    int64_t T = 0;
+    for (tmpnn_pdb_t *h : ok) T += tmpnn_pdb_length(h);
+    if (!ok.empty() && T > 0 && T < (1 << 24)) {
+        const int n = (int)ok.size();
+        std::vector<float> X((size_t)T * 12), mask(T), ca(T), table((size_t)T * 21);
+        std::vector<int32_t> S(T), ridx(T), cenc(T), off(n + 1), nb(T);
+        if (tmpnn_pdb_pack_batch(ok.data(), n, threads, T - 1, X.data(), S.data(), mask.data(), ridx.data(), cenc.data(), ca.data(), off.data()) != TMPNN_E_WORKSPACE) return 3;
+        if (tmpnn_pdb_pack_batch(ok.data(), n, threads, T, X.data(), S.data(), mask.data(), ridx.data(), cenc.data(), ca.data(), off.data()) != TMPNN_OK) return 3;
+        for (int64_t i = 0; i < T * 21; ++i) table[i] = (float)((i * 2654435761u % 20011) - 10000) * 1.37e-3f;
+        for (int64_t i = 0; i < T; ++i) nb[i] = (int32_t)(i % 37) - 1;
+        std::vector<const char *> seqs;
+        for (tmpnn_pdb_t *h : ok) seqs.push_back(tmpnn_pdb_seq(h));
+        std::vector<int64_t> tri;
+        for (int i = 0; i < n; ++i)
+            for (int32_t pos = 0; pos < off[i + 1] - off[i]; pos += 7) { tri.push_back(i); tri.push_back(pos); tri.push_back((pos * 3) % 20); }
+        for (int schema = 0; schema < 2; ++schema)
+            for (int flags = 0; flags < 4; ++flags) {
+                tmpnn_csv_t *c = nullptr;
+                if (tmpnn_csv_open("/dev/null", schema, &c) != TMPNN_OK) return 4;
+                if (tmpnn_csv_write_ssm(c, table.data(), 21, off.data(), n, seqs.data(), names.data(), flags & 1 ? nb.data() : nullptr, "Thermo,MPNN",
+                                        "a \"quoted\" set", nullptr, "A", flags, threads) != TMPNN_OK) return 4;
+                if (schema == 0 && tmpnn_csv_write_listed(c, table.data(), 21, off.data(), n, seqs.data(), names.data(), nb.data(), "m", "d",
+                                                          tri.data(), (int64_t)tri.size() / 3) != TMPNN_OK) return 4;
+                int64_t rows = 0, bytes = 0;
+                if (tmpnn_csv_close(c, &rows, &bytes) != TMPNN_OK || rows < 0 || bytes <= 0) return 4;
+            }
+    }
+    for (tmpnn_pdb_t *h : ok) tmpnn_pdb_free(h);
     printf("batch %d\n", rc);
     return 0;
 }

@@ -1127,11 +1127,16 @@ def test_bench_contract_line():
     import sys
     repo = os.path.dirname(os.path.dirname(GOLDEN))
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--proteins-per-gpu", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                        "--proteins-per-gpu", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TMPNN_E2E_FILES="48"))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    e2e = d["end_to_end"]                                # PDB files -> CSV / binary wall clock (48 files here, 1 024 by default)
+    assert e2e["files"] == 48 and e2e["to_csv"]["rows"] == e2e["preds"] and e2e["to_npz"]["rows"] == e2e["residues"], e2e
+    assert e2e["to_csv"]["preds_per_s"] > 0 and e2e["to_npz"]["preds_per_s"] > 0 and e2e["custom_inference_2OCJ"]["rows"] == 3880
+    assert d["roofline"]["issue"] is None or 0 < d["roofline"]["issue"]["frac"] < 1.5
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that refreshes every artefact under profiles/ for round $1 (e.g. r02). Run on the GPU box:
 #   tools/measure_round.sh r03        -> gpurun_out/$1_*  (copy into profiles/ afterwards)
-R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r03}; O=$R/gpurun_out
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r04}; O=$R/gpurun_out
 mkdir -p $O
 cd $R
 bash tools/pmc_traffic.sh > $O/${TAG}_pmc_traffic.log 2>&1
@@ -20,5 +20,12 @@ TMPNN_BENCH_ONE_DEVICE=1 TMPNN_BENCH_BACKEND=gloo python bench.py --gpus 2 --ste
 TMPNN_BENCH_FORCE_GROUP=1 python bench.py --steps 20 --warmup 5 --no-extras > $O/${TAG}_bench_rccl_1rank.json 2> $O/${TAG}_bench_rccl_1rank.err
 bash tools/pmc_sq.sh > $O/${TAG}_pmc_sq.log 2>&1
 cp $O/pmc_sq_summary.txt $O/${TAG}_pmc_sq_summary.txt
+# round 4: the end-to-end leg on its own, the kernel-boundary probe (+ its rocprofv3 trace), the margin probe
+python tools/e2e_bench.py > $O/${TAG}_e2e.json 2> $O/${TAG}_e2e.err
+python tools/gap_probe.py > $O/${TAG}_gap_probe.json 2> $O/${TAG}_gap_probe.err
+( cd /tmp && export TMPDIR=/tmp && rm -rf $O/gaptrace_$TAG && rocprofv3 --kernel-trace --output-format csv -d $O/gaptrace_$TAG -o gap -- python $R/tools/gap_probe.py --trace > /dev/null 2> $O/${TAG}_gaptrace.err )
+python tools/gap_probe.py --gaps $(find $O/gaptrace_$TAG -name "*kernel_trace.csv" | head -1) > $O/${TAG}_gap_trace_summary.json 2>> $O/${TAG}_gaptrace.err
+rm -rf $O/gaptrace_$TAG
+python tools/margin_probe.py > $O/${TAG}_margin_probe.json 2> $O/${TAG}_margin_probe.err
 rm -rf $O/prof_$TAG/*/*.db 2>/dev/null
 tail -c 600 $O/${TAG}_bench_full.err; head -c 400 $O/${TAG}_bench_full.json; echo; head -9 $O/${TAG}_bench_kernel_stats_timed.csv; tail -12 $O/${TAG}_pmc_traffic.log
