@@ -617,3 +617,25 @@ print('compat ok')
     env = dict(os.environ, PYTHONPATH=os.path.join(repo, "compat"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
     assert r.returncode == 0 and "compat ok" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
+def test_native_csv_streams_a_very_long_protein_in_blocks(tmp_path):
+    """The reference's layout repeats the whole sequence in every row, so a protein's text grows with L^2: beyond 64 MB the
+    native writer waits for the protein's turn and streams blocks of positions instead of buffering it whole. Same bytes."""
+    from thermompnn_amd import native_csv, ssm_scan
+    rng = np.random.default_rng(3)
+    L = 1900                                                   # 38 000 rows x 1.9 KB = 74 MB of text
+    seqs = ["".join(AA20[k] for k in rng.integers(0, 20, 40)), "".join(AA20[k] for k in rng.integers(0, 20, L)),
+            "".join(AA20[k] for k in rng.integers(0, 20, 25))]
+    tabs = [rng.normal(size=(len(s), 21)).astype(np.float32) for s in seqs]
+    names = ["small_a", "giant", "small_b"]
+    rows = []
+    for i in range(3):
+        rows += ssm_scan.rows_for_protein({"seq": seqs[i], "name": names[i]}, tabs[i], None, "ThermoMPNN", "custom", False, True)
+    ssm_scan.write_csv(rows, str(tmp_path / "py.csv"))
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int32)
+    with native_csv.CsvWriter(str(tmp_path / "nat.csv")) as w:
+        w.write_ssm(np.concatenate(tabs), off, seqs, names, include_cys=True, n_threads=3)
+    assert w.rows == len(rows) and w.bytes > (64 << 20)
+    import filecmp
+    assert filecmp.cmp(str(tmp_path / "py.csv"), str(tmp_path / "nat.csv"), shallow=False)

@@ -199,56 +199,88 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
             head += f_model; head += ","; head += f_data; head += ",";
             const int64_t nrows = first[i + 1] - first[i];
             const size_t per_row = 20 + head.size() + 26 + 12 + 4 + 12 + 2 + f_name.size() + f_chain.size() + 4;
-            buf.resize((size_t)nrows * per_row + 64);
-            char *o = buf.data();
-            int64_t row = first[i];
-            for (int32_t pos = 0; pos < L; ++pos) {
-                const char wt = seq[pos];
-                if (wt == '-') continue;
-                const float *t = tab + (size_t)pos * ld;
-                char best = 0;
-                if (pick) {                                       // idxmin: first minimum wins (SSM.py:32-42)
-                    int bi = -1;
-                    double bv = 0;
-                    for (int a = 0; a < 20; ++a) {
-                        if (!cys && kAA20[a] == 'C') continue;
-                        if (bi < 0 || (double)t[a] < bv) { bi = a; bv = t[a]; }
+            // rows of positions [p0, p1) -> buf (from its start); returns the running index after them
+            auto format = [&](int32_t p0, int32_t p1, int64_t row, size_t *len_out) {
+                char *o = buf.data();
+                for (int32_t pos = p0; pos < p1; ++pos) {
+                    const char wt = seq[pos];
+                    if (wt == '-') continue;
+                    const float *t = tab + (size_t)pos * ld;
+                    char best = 0;
+                    if (pick) {                                       // idxmin: first minimum wins (SSM.py:32-42)
+                        int bi = -1;
+                        double bv = 0;
+                        for (int a = 0; a < 20; ++a) {
+                            if (!cys && kAA20[a] == 'C') continue;
+                            if (bi < 0 || (double)t[a] < bv) { bi = a; bv = t[a]; }
+                        }
+                        best = kAA20[bi];
                     }
-                    best = kAA20[bi];
-                }
-                for (int a = 0; a < (pick ? 1 : 20); ++a) {
-                    if (!pick && !cys && kAA20[a] == 'C') continue;
-                    o = put_int(o, row++);
-                    memcpy(o, head.data(), head.size()); o += head.size();
-                    o += repr_double((double)t[a], o);
-                    *o++ = ',';
-                    o = put_int(o, pos);
-                    *o++ = ','; *o++ = wt; *o++ = ','; *o++ = kAA20[a]; *o++ = ',';
-                    if (schema == 0) {
-                        if (nb) o = put_int(o, nb[pos]);
+                    for (int a = 0; a < (pick ? 1 : 20); ++a) {
+                        if (!pick && !cys && kAA20[a] == 'C') continue;
+                        o = put_int(o, row++);
+                        memcpy(o, head.data(), head.size()); o += head.size();
+                        o += repr_double((double)t[a], o);
                         *o++ = ',';
-                        if (best) *o++ = best;
-                        *o++ = ',';
-                        memcpy(o, f_name.data(), f_name.size()); o += f_name.size();
-                    } else {
-                        memcpy(o, f_name.data(), f_name.size()); o += f_name.size();
-                        *o++ = ',';
-                        memcpy(o, f_chain.data(), f_chain.size()); o += f_chain.size();
+                        o = put_int(o, pos);
+                        *o++ = ','; *o++ = wt; *o++ = ','; *o++ = kAA20[a]; *o++ = ',';
+                        if (schema == 0) {
+                            if (nb) o = put_int(o, nb[pos]);
+                            *o++ = ',';
+                            if (best) *o++ = best;
+                            *o++ = ',';
+                            memcpy(o, f_name.data(), f_name.size()); o += f_name.size();
+                        } else {
+                            memcpy(o, f_name.data(), f_name.size()); o += f_name.size();
+                            *o++ = ',';
+                            memcpy(o, f_chain.data(), f_chain.size()); o += f_chain.size();
+                        }
+                        *o++ = '\n';
                     }
-                    *o++ = '\n';
                 }
+                *len_out = (size_t)(o - buf.data());
+                return row;
+            };
+            // The layout repeats the whole sequence in every row, so a protein's text grows with L^2 (L = 512: 5.8 MB; L = 35 000:
+            // 24 GB). Up to kWholeProtein bytes a protein is formatted as one buffer, off the critical path, and committed in order;
+            // beyond that it waits for its turn and streams position blocks of about kBlock bytes straight to its place in the file.
+            constexpr size_t kWholeProtein = (size_t)64 << 20, kBlock = (size_t)8 << 20;
+            const size_t rows_per_pos = pick ? 1 : (cys ? 20 : 19);
+            if ((size_t)nrows * per_row <= kWholeProtein) {
+                buf.resize((size_t)nrows * per_row + 64);
+                size_t len = 0;
+                format(0, L, first[i], &len);
+                int64_t at;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return commit == i; });
+                    at = off;
+                    off += (int64_t)len;
+                    ++commit;
+                }
+                cv.notify_all();
+                if (len && !write_all_at(c->fd, buf.data(), len, at)) failed = true;
+            } else {
+                const int32_t step = (int32_t)std::max<size_t>(1, kBlock / (rows_per_pos * per_row));
+                buf.resize((size_t)step * rows_per_pos * per_row + 64);
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return commit == i; });
+                }
+                int64_t row = first[i], at = off;                  // (this thread owns the tail of the file until it bumps `commit`)
+                for (int32_t p0 = 0; p0 < L; p0 += step) {
+                    size_t len = 0;
+                    row = format(p0, std::min<int32_t>(L, p0 + step), row, &len);
+                    if (len && !write_all_at(c->fd, buf.data(), len, at)) failed = true;
+                    at += (int64_t)len;
+                }
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    off = at;
+                    ++commit;
+                }
+                cv.notify_all();
             }
-            const size_t len = (size_t)(o - buf.data());
-            int64_t at;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return commit == i; });
-                at = off;
-                off += (int64_t)len;
-                ++commit;
-            }
-            cv.notify_all();
-            if (len && !write_all_at(c->fd, buf.data(), len, at)) failed = true;
         }
     };
     n_threads = std::max(1, std::min(n_threads, std::max(n, 1)));
