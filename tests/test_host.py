@@ -635,7 +635,7 @@ def test_native_csv_streams_a_very_long_protein_in_blocks(tmp_path):
     ssm_scan.write_csv(rows, str(tmp_path / "py.csv"))
     off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int32)
     with native_csv.CsvWriter(str(tmp_path / "nat.csv")) as w:
-        w.write_ssm(np.concatenate(tabs), off, seqs, names, include_cys=True, n_threads=3)
+        w.write_ssm(np.concatenate(tabs), off, seqs, [n.strip(".pdb") for n in names], include_cys=True, n_threads=3)   # (SSM.py:139's strip)
     assert w.rows == len(rows) and w.bytes > (64 << 20)
     import filecmp
     assert filecmp.cmp(str(tmp_path / "py.csv"), str(tmp_path / "nat.csv"), shallow=False)
