@@ -330,8 +330,14 @@ def end_to_end(eng, n_files=None, budget_note=None):
                                                           "wait_for_gpu": st.gpu_wait_s, "write": st.sink_s},
                     "note": "stage_busy_s are per-stage busy seconds of concurrently running stages (their sum exceeds wall_s)"}
 
-        out["to_csv"] = min((leg("csv") for _ in range(2)), key=lambda r: r["wall_s"])
-        out["to_npz"] = min((leg("npz") for _ in range(3)), key=lambda r: r["wall_s"])
+        def best_of(name, n):
+            runs = [leg(name) for _ in range(n)]
+            best = min(runs, key=lambda r: r["wall_s"])
+            best["wall_s_all_runs"] = [r["wall_s"] for r in runs]     # (writing 2.4 GB of text to tmpfs varies 2 x between runs)
+            return best
+
+        out["to_csv"] = best_of("csv", 3)
+        out["to_npz"] = best_of("npz", 3)
         # stage ceilings measured alone: the parser over all files, the forward over the same ragged chunks
         import ctypes as C2
         lib = _lib.load()
@@ -349,15 +355,19 @@ def end_to_end(eng, n_files=None, budget_note=None):
         # the single-structure script (BASELINE configs[0] shape): examples-style 2OCJ -> CSV
         pdb = os.path.join(REPO, "tests", "golden", "2OCJ.pdb")
         if os.path.exists(pdb):
+            import contextlib
+            import io
             t1 = time.perf_counter()
-            custom_inference.main(["--pdb", pdb, "--chain", "A", "--synthetic_weights", "0", "--out_dir", d])
+            with contextlib.redirect_stdout(io.StringIO()):          # (the script announces its output file on stdout)
+                custom_inference.main(["--pdb", pdb, "--chain", "A", "--synthetic_weights", "0", "--out_dir", d])
             cold = time.perf_counter() - t1
             model = custom_inference.load_model("", "", 0, device=eng.device)
             custom_inference.ssm_to_csv(model, pdb, "A", os.path.join(d, "w.csv"))
-            t1 = time.perf_counter()
-            for _ in range(5):
+            warm = 1e9
+            for _ in range(7):
+                t1 = time.perf_counter()
                 custom_inference.ssm_to_csv(model, pdb, "A", os.path.join(d, "w.csv"))
-            warm = (time.perf_counter() - t1) / 5
+                warm = min(warm, time.perf_counter() - t1)
             t1 = time.perf_counter()
             custom_inference.write_csv(custom_inference.ssm_rows(model, pdb, "A"), os.path.join(d, "r.csv"))
             shaped = time.perf_counter() - t1

@@ -71,3 +71,14 @@ def test_rocprof_timed_stats_keeps_the_timed_launches_only(tmp_path):
     assert int(edge["TimedLaunches"]) == 6 and float(edge["AvgNs"]) == 300.0 and int(edge["AllLaunches"]) == 21
     assert abs(float(edge["AvgNsAllLaunches"]) - (15 * 400 + 6 * 300) / 21) < 0.1
     assert float(out["void knn_kernel<4>"]["AvgNs"]) == 60.0 and "unrelated_kernel" not in out
+
+
+def test_committed_isa_counts_belong_to_the_committed_kernel_sources():
+    """bench.py's issue roof reads profiles/r*_isa_counts.json and refuses a file made from other sources (its `source_stamp` is
+    the hash of thermompnn_amd/csrc): regenerate it with `python tools/isa_counts.py` whenever a kernel source changes."""
+    import bench
+    c = bench.isa_counts("enc_edge")
+    assert c is not None, "profiles/r*_isa_counts.json is stale: run python tools/isa_counts.py"
+    assert c["mfma:v_mfma_f32_16x16x32_f16"] == 108 and c["valu"] + c["valu_packed"] + c["valu_trans"] > 300
+    ir = bench.issue_roof("enc_edge", 16384, 256, 2.3, 0.30)
+    assert 0.5 < ir["frac"] < 1.0 and ir["tiles_per_cu"] == 64 and ir["cycles_per_wavefront_tile"] == ir["mfma_cycles"] + ir["valu_cycles"]
