@@ -12,6 +12,9 @@
 #ifndef TM_PROF_TID
 #define TM_PROF_TID 0   // thread of workgroup 0 whose cycle counter the TMPNN_*_PROF phase timers read (448 = wavefront 7, lowest issue priority)
 #endif
+#ifndef TM_EDGE_Y_ALIAS
+#define TM_EDGE_Y_ALIAS 1   // 0: a third plane tile for GEMM 2's output (77.5 KB of LDS, offsets above 64 KB): the rounds 1-3 form, A/B only
+#endif
 #ifndef TM_EDGE_PF
 #define TM_EDGE_PF 2     // the same for the edge-update kernel's three 12-step GEMMs: 0.339 ms at 0, 0.329 at 1, 0.323 at 2, 0.326 at 3-4
 #endif
@@ -303,7 +306,14 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     static_assert(TILEB >= TM_TILE * TM_H * 4, "the fp32 LayerNorm tile is aliased on the x planes");
     __shared__ __attribute__((aligned(16))) char tE[TILEB];
     __shared__ __attribute__((aligned(16))) char tX[TILEB];              // x planes; later the fp32 LayerNorm input
+    // GEMM 2's output planes live where the e planes were: GEMM 1 was their last reader (every wavefront is past the barrier behind
+    // it), the next tile's e planes are written only behind the barrier that follows GEMM 3. Two plane tiles instead of three:
+    // 53 KB of LDS, every LDS offset below 64 KB (an offset above costs an address VGPR + a v_or each: 10 VALU per tile).
+#if TM_EDGE_Y_ALIAS
+    char *const tY = tE;
+#else
     __shared__ __attribute__((aligned(16))) char tY[TILEB];
+#endif
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT_LD];
     __shared__ int s_idx[2][TM_TILE];
     float *tO = reinterpret_cast<float *>(tX);
@@ -827,7 +837,14 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
     static_assert(TILEB >= TM_TILE * TM_H * 4, "the fp32 LayerNorm tile is aliased on the x planes");
     __shared__ __attribute__((aligned(16))) char tE[TILEB];
     __shared__ __attribute__((aligned(16))) char tX[TILEB];              // x planes; the fp32 LayerNorm input; the message pass's tA
+    // GEMM 2's output planes live where the e planes were: GEMM 1 was their last reader (every wavefront is past the barrier behind
+    // it), the next tile's e planes are written only behind the barrier that follows GEMM 3. Two plane tiles instead of three:
+    // 53 KB of LDS, every LDS offset below 64 KB (an offset above costs an address VGPR + a v_or each: 10 VALU per tile).
+#if TM_EDGE_Y_ALIAS
+    char *const tY = tE;
+#else
     __shared__ __attribute__((aligned(16))) char tY[TILEB];
+#endif
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT_LD];
     __shared__ int s_idx[TM_TILE];
     __shared__ float s_ma[TM_TILE];
