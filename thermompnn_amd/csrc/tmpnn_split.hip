@@ -12,6 +12,10 @@
 #ifndef TM_PROF_TID
 #define TM_PROF_TID 0   // thread of workgroup 0 whose cycle counter the TMPNN_*_PROF phase timers read (448 = wavefront 7, lowest issue priority)
 #endif
+#ifndef TM_EDGE_UNROLL2
+#define TM_EDGE_UNROLL2 0   // 1: the edge update's tile loop unrolled by two with the e-tile register sets swapping roles (no loop-carried copy:
+                            // 422 instead of 437 VALU per tile, 234 VGPRs, no spill). Measured in one call, three alternations: 0.2948 vs 0.2932 ms — nil; off
+#endif
 #ifndef TM_EDGE_Y_ALIAS
 #define TM_EDGE_Y_ALIAS 1   // 0: a third plane tile for GEMM 2's output (77.5 KB of LDS, offsets above 64 KB): the rounds 1-3 form, A/B only
 #endif
@@ -364,6 +368,122 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     int nidx = -1;
     if (i < tr.end && tid < TM_TILE) nidx = a.E_idx[(size_t)(i + tr.step < tr.end ? i + tr.step : i) * TM_KS + tid];
     mark(-1);
+#if TM_EDGE_UNROLL2
+    // The loop body twice per trip with the two e-tile register sets swapping roles (e_a current / e_b next, then the reverse) and the
+    // s_idx buffer index a constant: the loop-carried "e_cur = e_nxt" (12 v_mov per tile) disappears. Same operations, same order.
+    f4 (&e_a)[3] = e_cur, (&e_b)[3] = e_nxt;
+    auto tile_iter = [&](f4 (&e_cur)[3], f4 (&e_nxt)[3], const int cur) {
+            float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
+            const int inext = i + tr.step;
+            const bool has_next = inext < tr.end;
+            const int ipf = has_next ? inext : i;              // prefetch target (the last iteration re-reads its own tile)
+            const int ipf2 = ipf + tr.step < tr.end ? ipf + tr.step : ipf;
+            const int nidx_pub = nidx;                         // list of tile ipf, requested during the previous iteration
+            {
+                if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf2 * TM_KS + tid];
+                const float *src = a.hE + (size_t)ipf * TM_KS * TM_H;         // wave-uniform base + per-thread offset
+    #if TM_ABL_NOLOAD
+    #pragma unroll
+                for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = e_cur[rb];
+                (void)src;
+    #else
+    #pragma unroll
+                for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = ld4(src + (eoff + 16 * rb * TM_H));
+    #endif
+            }
+            f4 acc[3][1];
+    #pragma unroll
+            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
+            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tE, w11, acc, lane);
+            mark(0);
+            {   // the three row blocks' GELUs as six independent chains, then the three splits
+                f4 g[3];
+    #pragma unroll
+                for (int rb = 0; rb < 3; ++rb) g[rb] = gelu4(acc[rb][0]);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int rb = 0; rb < 3; ++rb) store_split<SP>(tX, 16 * rb + m, c4, g[rb]);
+            }
+            if (tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx_pub;
+            mark(1);
+            __syncthreads();
+            mark(2);
+
+            gai = ld4(a.P + (size_t)ipf * 256 + ucol);
+    #pragma unroll
+            for (int rb = 0; rb < 3; ++rb) gcj[rb] = ld4(prow_of(s_idx[cur ^ 1][16 * rb + m], ipf));
+    #pragma unroll
+            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
+            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tX, w12, acc, lane);
+            mark(3);
+            {
+                f4 g[3];
+    #pragma unroll
+                for (int rb = 0; rb < 3; ++rb) g[rb] = gelu4(acc[rb][0]);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int rb = 0; rb < 3; ++rb) store_split<SP>(tY, 16 * rb + m, c4, g[rb]);
+            }
+            mark(4);
+            __syncthreads();
+            mark(5);
+
+    #pragma unroll
+            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
+            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tY, w13, acc, lane);
+            mark(6);
+    #pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                const f4 v = e_cur[rb] + acc[rb][0];                             // residual on the fp32 tile
+                st4(tO + chunk_off(16 * rb + m, c4), v);
+                #if TM_ABL_NOLN
+                (void)q;
+    #else
+                row_stats_partial16(v, &s_stat[16 * rb + m][2 * wv], q);
+    #endif
+            }
+            mark(7);
+            __syncthreads();                                                     // tE free, tO + stats complete
+            mark(8);
+
+    #pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                store_split<SP>(tE, 16 * rb + m, c4, e_nxt[rb]);
+                
+            }
+            touch(gai);                                    // the next tile's gathers have long arrived: take their vmcnt wait
+    #pragma unroll
+            for (int rb = 0; rb < 3; ++rb) touch(gcj[rb]); // here, in front of the stores below (see touch())
+    #pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int row = 6 * wv + 2 * it + (lane >> 5);
+                float mean = 0.f, rstd = 1.f;
+    #if !TM_ABL_NOLN
+                row_stats_finish8d(&s_stat[row][0], lane, mean, rstd);
+    #endif
+                // (x - mean) rstd g + be as y = x s + t with s = rstd g, t = be - mean s: three packed fmas / muls per half row
+                const f4 x4 = ld4(tO + chunk_off(row, c32));
+                const f2 s01 = f2{g4.x, g4.y} * rstd, s23 = f2{g4.z, g4.w} * rstd;
+                const f2 t01 = __builtin_elementwise_fma(f2{-mean, -mean}, s01, f2{be4.x, be4.y});
+                const f2 t23 = __builtin_elementwise_fma(f2{-mean, -mean}, s23, f2{be4.z, be4.w});
+                const f2 y01 = __builtin_elementwise_fma(f2{x4.x, x4.y}, s01, t01), y23 = __builtin_elementwise_fma(f2{x4.z, x4.w}, s23, t23);
+                const f4 y = f4{y01.x, y01.y, y23.x, y23.y};
+                // rows without a neighbour keep the zeros the featurizer wrote: store zeros again (no divergent branch)
+                st4(tile_g + (soff + 2 * it * TM_H), s_idx[cur][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
+            }
+            
+            mark(9);
+            __syncthreads();
+            mark(10);
+    };
+    while (i < tr.end) {
+        tile_iter(e_a, e_b, 0);
+        i += tr.step;
+        if (!(i < tr.end)) break;
+        tile_iter(e_b, e_a, 1);
+        i += tr.step;
+    }
+#else
     for (; i < tr.end; i += tr.step) {
         float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
         const int inext = i + tr.step;
@@ -468,6 +588,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         __syncthreads();
         mark(10);
     }
+#endif
 }
 
 int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
