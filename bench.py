@@ -101,12 +101,14 @@ def kernel_roofs(name, T, edges, avg_ms, mode):
 
 
 def kernel_source_stamp():
-    """Hash of the kernel sources: a PMC file measured on other kernels must not be quoted for these."""
+    """Hash of the DEVICE sources (csrc/*.hip + the headers they include): a PMC or ISA-count file measured on other kernels must
+    not be quoted for these. The host-only translation units (tmpnn_pdb.cpp, tmpnn_csv.cpp) are not part of it (round 4: an edit of
+    the CSV writer must not void the kernels' evidence)."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(REPO, "thermompnn_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith((".hip", ".h")):
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
