@@ -129,9 +129,13 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
     from .native_pdb import _chains_arg
     parse_threads = parse_threads or max(1, usable_cpus() - 2)
     dev = engine.device
+    # pinned staging slots are kept on the engine between scans (pinning a few MB costs milliseconds: hipHostMalloc)
+    pool: List[_Staging] = getattr(engine, "_staging_pool", None) or []
+    engine._staging_pool = []                              # (taken: a concurrent scan on the same engine gets fresh ones)
     free_slots: "queue.Queue[_Staging]" = queue.Queue()
-    for _ in range(depth):
-        free_slots.put(_Staging())
+    slots = [pool.pop() if pool else _Staging() for _ in range(depth)]
+    for sl in slots:
+        free_slots.put(sl)
     q_parsed: "queue.Queue" = queue.Queue(maxsize=depth)
     q_done: "queue.Queue" = queue.Queue(maxsize=depth)
     errors: List[BaseException] = []
@@ -302,6 +306,7 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
         q_done.put(None)
         tw.join()
         tp.join()
+        engine._staging_pool = slots                       # every slot is back in free_slots by now (both threads have ended)
     stats.wall_s = time.perf_counter() - t_wall
     if errors:
         raise errors[0]
