@@ -245,3 +245,22 @@ def test_non_default_head_configurations_match_the_reference(tmp_path, suffix):
     with pytest.raises(TmpnnError):
         eng.ddg_head_generic([res["hidden"][2]], f[1][0], model.prot_mpnn.W_s.weight, [torch.zeros(21, 100)], [torch.zeros(21)],
                              model.ddg_out.weight, model.ddg_out.bias)
+
+
+def test_pipeline_propagates_a_failing_consumer_and_stays_usable(tmp_path, engine):
+    """A sink that raises (a full disk, a bad callback) stops the scan with ITS exception — no hang, no leaked staging slot —
+    and the same engine runs the next scan normally (the pinned slots are kept on the engine between scans)."""
+    from thermompnn_amd import pipeline, ssm_scan
+    paths = _pdb_set(tmp_path, n=12, seed=9)
+    seen = []
+
+    def sink(ch):
+        seen.append(ch.index)
+        if ch.index == 1:
+            raise OSError("disk full (test)")
+
+    with pytest.raises(OSError, match="disk full"):
+        pipeline.scan_files(engine, paths, ["A"] * len(paths), sink, chunk_files=3)
+    assert seen[:2] == [0, 1] and len(engine._staging_pool) == 3
+    n, stats = ssm_scan.scan_to_file(engine, paths, ["A"] * len(paths), str(tmp_path / "after.npz"), chunk_files=3)
+    assert stats.chunks >= 4 and n == np.load(tmp_path / "after.npz")["ddg"].shape[0]
