@@ -16,6 +16,7 @@ from .datasets import ALPHABET
 from .pdb_io import tied_featurize
 from .protein_mpnn_utils import ProteinMPNN, _EngineOwner, _register_tree
 
+_AA_INDEX = {a: i for i, a in enumerate(ALPHABET)}
 HIDDEN_DIM = 128
 EMBED_DIM = 128
 VOCAB_DIM = 21
@@ -95,17 +96,15 @@ class TransferModel(_EngineOwner):
             if self.generic_head:
                 res["ddg"], z_generic = self._generic_tables(eng, res["hidden"], S[0])
             ddg = res["ddg"]                                        # [L,21]: (w z_a + b) - (w z_wt + b), wt = S
-            pos, aa, wt = [], [], []
-            for m in mutations:
-                if m is not None:
-                    pos.append(m.position)
-                    aa.append(ALPHABET.index(m.mutation))
-                    wt.append(ALPHABET.index(m.wildtype))
-            if not pos:
+            live = [m for m in mutations if m is not None]
+            if not live:
                 return [None for _ in mutations], None
-            pos_t = torch.tensor(pos, device=device)
-            aa_t = torch.tensor(aa, device=device)
-            wt_t = torch.tensor(wt, device=device)
+            # (host side of a 20 x L scan: three list comprehensions and ONE host-to-device copy, not 3 x 20 L appends and 3 copies)
+            code = _AA_INDEX
+            sel = torch.tensor([[m.position for m in live],
+                                [code[m.mutation] if m.mutation in code else ALPHABET.index(m.mutation) for m in live],
+                                [code[m.wildtype] if m.wildtype in code else ALPHABET.index(m.wildtype) for m in live]], device=device)
+            pos_t, aa_t, wt_t = sel[0], sel[1], sel[2]
             if self.subtract_mut and bool((S[0][pos_t] == wt_t).all()):
                 vals = ddg[pos_t, aa_t]
             else:   # a stated wild type that differs from the structure, or subtract_mut=False: use z directly
@@ -113,11 +112,5 @@ class TransferModel(_EngineOwner):
                 z = z_generic if self.generic_head else eng.ddg_head(hid[2], hid[1], S[0], want_z=True)[1]
                 zz = z * self.ddg_out.weight.view(()) + self.ddg_out.bias.view(())
                 vals = zz[pos_t, aa_t] - zz[pos_t, wt_t] if self.subtract_mut else zz[pos_t, aa_t]
-        out, k = [], 0
-        for m in mutations:
-            if m is None:
-                out.append(None)
-            else:
-                out.append({"ddG": vals[k:k + 1]})
-                k += 1
-        return out, None
+        pieces = iter(vals.split(1))                               # Tensor[1] views, made in one C++ call (transfer_model.py:117-119)
+        return [None if m is None else {"ddG": next(pieces)} for m in mutations], None
