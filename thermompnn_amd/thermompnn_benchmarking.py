@@ -52,14 +52,14 @@ class ProteinMPNNBaseline(_EngineOwner):
         feats = tied_featurize([pdb[0]], device, None, None, None, None, None, None, ca_only=False)
         X, S, mask, chain_M, chain_enc, residue_idx = feats[0], feats[1], feats[2], feats[4], feats[5], feats[12]
         *_, log_probs = self.prot_mpnn(X, S, mask, chain_M, residue_idx, chain_enc, None)
-        out = []
-        for mut in mutations:
-            if mut is None:
-                out.append(None)
-                continue
-            pred = log_probs[0, mut.position, ALPHABET.index(mut.mutation)]
-            out.append({"ddG": -torch.unsqueeze(pred, 0), "dTm": torch.unsqueeze(pred, 0)})
-        return out, log_probs
+        live = [m for m in mutations if m is not None]
+        if not live:
+            return [None for _ in mutations], log_probs
+        # one gather for every listed mutant (the reference indexes log_probs once per mutation, :55-62), then Tensor[1] views
+        sel = torch.tensor([[m.position for m in live], [ALPHABET.index(m.mutation) for m in live]], device=log_probs.device)
+        pred = log_probs[0][sel[0], sel[1]]
+        dtm, ddg = iter(pred.split(1)), iter((-pred).split(1))
+        return [None if m is None else {"ddG": next(ddg), "dTm": next(dtm)} for m in mutations], log_probs
 
 
 def get_trained_model(model_name, config, checkpt_dir="models/", override_custom=False, allow_pickle=None):
