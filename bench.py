@@ -372,9 +372,11 @@ def end_to_end(eng, n_files=None, budget_note=None):
                 t1 = time.perf_counter()
                 custom_inference.ssm_to_csv(model, pdb, "A", os.path.join(d, "w.csv"))
                 warm = min(warm, time.perf_counter() - t1)
-            t1 = time.perf_counter()
-            custom_inference.write_csv(custom_inference.ssm_rows(model, pdb, "A"), os.path.join(d, "r.csv"))
-            shaped = time.perf_counter() - t1
+            shaped = 1e9
+            for _ in range(3):                                       # (the first call also pays one-time allocations)
+                t1 = time.perf_counter()
+                custom_inference.write_csv(custom_inference.ssm_rows(model, pdb, "A"), os.path.join(d, "r.csv"))
+                shaped = min(shaped, time.perf_counter() - t1)
             out["custom_inference_2OCJ"] = {"main_s": cold, "pdb_to_csv_warm_s": warm, "reference_shaped_api_s": shaped,
                                             "rows": 3880, "note": "main_s = the whole script in-process (synthetic checkpoint written "
                                             "and loaded, weights repacked, parse, forward, CSV); pdb_to_csv_warm_s = parse + forward + "
