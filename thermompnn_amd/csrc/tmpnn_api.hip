@@ -645,9 +645,15 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     // h_V starts at zero (:1228): the k-NN kernel writes that state and its message projection [b1 | 0] as it goes, and
     // node_update of every layer writes the projection the next message pass needs into ws.P — 18 launches per forward
     // (28 when every projection and the zero state are launches of their own)
-    TRY(launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, nullptr, st, KnnInit{hV[0], ws.P, w->enc[0].b1, status_opt}));
-    TRY(launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, hE, nullptr, st));
     static const bool fuse_small = TM_DBG_FLAG("TMPNN_FUSE_SMALL", true);     // (A/B switch in the debug library only)
+    const KnnInit kinit{hV[0], ws.P, w->enc[0].b1, status_opt};
+    if (fuse_small && max_len <= 256 && featurize_fusable(w, T)) {             // one tile per workgroup: k-NN inside the featurizer launch
+        const KnnFuse kf{mask, offsets, n_proteins, max_len, K, E_idx, D_nb, kinit};
+        TRY(launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, hE, nullptr, st, &kf));
+    } else {
+        TRY(launch_knn(X, mask, offsets, n_proteins, T, max_len, K, E_idx, D_nb, nullptr, st, kinit));
+        TRY(launch_featurize(w, X, residue_idx, chain_enc, E_idx, D_nb, T, hE, nullptr, st));
+    }
     if (fuse_small && edge_msg_fusable(tm_matmul_mode(), T)) {
         // One tile per workgroup (a single protein, a few short ones): the edge update of encoder layer l and the message pass of
         // the layer after it are ONE launch (edge_msg_fused_kernel: no grid-wide dependency between them; 16 launches instead

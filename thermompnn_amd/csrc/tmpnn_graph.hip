@@ -324,6 +324,38 @@ __device__ __forceinline__ bool knn_row_sel(unsigned (*sel)[2], const float *__r
     return true;
 }
 
+// One residue's neighbour row by ONE wavefront (the body of knn_kernel's loop; the small-launch featurizer calls it too, so both
+// produce the same list, bit for bit): the zero state + first projection of the fused forward, the protein bounds, the max_len
+// guard, then the row in registers (NS candidates per lane) or through the LDS row `d` (NS = 0).
+template <int NS>
+__device__ __forceinline__ void knn_residue(float *d, unsigned (*sel)[2], const float *__restrict__ X, const float *__restrict__ mask,
+                                            const int32_t *__restrict__ offsets, int N, int max_len, int K, int32_t *__restrict__ E_idx,
+                                            float *__restrict__ D_nb, int32_t *__restrict__ status, const KnnInit &init, int sel_rows,
+                                            int i, int lane) {
+    if (init.hV0) {      // the fused forward: this residue's all-zero initial state and its projection (W . 0 + b = b exactly)
+        const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+        if (lane < 32) st4(init.hV0 + (size_t)i * TM_H + 4 * lane, z);
+        st4(init.P + (size_t)i * 256 + 4 * lane, lane < 32 ? ld4(init.ba + 4 * lane) : z);
+    }
+    int lo = 0, hi = N;                      // protein p with offsets[p] <= i < offsets[p+1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int s = offsets[lo], L = offsets[lo + 1] - s;
+    if (L > max_len) {      // the caller's max_len sized this wavefront's LDS row: a longer protein would overrun it
+        if (lane < TM_KS) { E_idx[(size_t)i * TM_KS + lane] = -1; D_nb[(size_t)i * TM_KS + lane] = 0.f; }
+        if (lane == 0 && status) atomicOr(status, TMPNN_STATUS_MAXLEN);
+        return;
+    }
+    const int Keff = K < L ? K : L;
+    if constexpr (NS > 0) {
+        if (!sel_rows || !knn_row_sel<NS>(sel, X, mask, i, s, L, Keff, lane, E_idx, D_nb))
+            knn_row_reg<NS>(X, mask, i, s, L, Keff, lane, E_idx, D_nb);
+    } else if (L > 512) knn_row<true>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
+    else knn_row<false>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
+}
+
 // NS = 0: rows of any length through LDS (knn_row); NS = 4 / 8: every row of the batch has at most 256 / 512 residues
 // (max_len says so) and runs in registers (knn_row_reg) — no dynamic LDS at all.
 template <int NS>
@@ -337,30 +369,8 @@ __global__ __launch_bounds__(TM_THREADS, NS == 8 ? 4 : 8) void knn_kernel(const 
     float *d = knn_lds + (size_t)wv * (max_len + (max_len >> 6) + 1);
     if (init.status_zero && tm_bid() == 0 && tm_tid() == 0) *init.status_zero = 0;   // (nothing in this launch ORs into it: status == nullptr)
 
-    for (int i = tm_bid() * 4 + wv; i < T; i += tm_nblk() * 4) {
-        if (init.hV0) {      // the fused forward: this residue's all-zero initial state and its projection (W . 0 + b = b exactly)
-            const f4 z = f4{0.f, 0.f, 0.f, 0.f};
-            if (lane < 32) st4(init.hV0 + (size_t)i * TM_H + 4 * lane, z);
-            st4(init.P + (size_t)i * 256 + 4 * lane, lane < 32 ? ld4(init.ba + 4 * lane) : z);
-        }
-        int lo = 0, hi = N;                      // protein p with offsets[p] <= i < offsets[p+1]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (offsets[mid] <= i) lo = mid; else hi = mid;
-        }
-        const int s = offsets[lo], L = offsets[lo + 1] - s;
-        if (L > max_len) {      // the caller's max_len sized this wavefront's LDS row: a longer protein would overrun it
-            if (lane < TM_KS) { E_idx[(size_t)i * TM_KS + lane] = -1; D_nb[(size_t)i * TM_KS + lane] = 0.f; }
-            if (lane == 0 && status) atomicOr(status, TMPNN_STATUS_MAXLEN);
-            continue;
-        }
-        const int Keff = K < L ? K : L;
-        if constexpr (NS > 0) {
-            if (!sel_rows || !knn_row_sel<NS>(s_sel[wv], X, mask, i, s, L, Keff, lane, E_idx, D_nb))
-                knn_row_reg<NS>(X, mask, i, s, L, Keff, lane, E_idx, D_nb);
-        } else if (L > 512) knn_row<true>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
-        else knn_row<false>(d, X, mask, i, s, L, Keff, lane, E_idx, D_nb);
-    }
+    for (int i = tm_bid() * 4 + wv; i < T; i += tm_nblk() * 4)
+        knn_residue<NS>(d, s_sel[wv], X, mask, offsets, N, max_len, K, E_idx, D_nb, status, init, sel_rows, i, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -566,8 +576,13 @@ __device__ __forceinline__ void tm_glds4(const void *src, unsigned lds) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
 }
 // PROF: phase timing (s_memtime deltas of thread 0 of workgroup 0, summed over its tiles) into prof[0..7] — TMPNN_FEAT_PROF=1
-template <typename SP, bool PROF = false, bool IMG = false>
-__global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, unsigned long long *prof = nullptr) {
+// KNN (small launches, one tile per workgroup): the neighbour row of the workgroup's residue is computed HERE by wavefront 0
+// (knn_residue<4>: T <= #CUs <= 256, so every protein fits the register form) while the other seven load their weight fragments — one
+// launch less in front of a single protein (2.5 us of dispatch + the start-up latency of a kernel, tools/gap_probe.py).
+struct KnnFuseArgs { const float *mask; const int32_t *offsets; int N, max_len, K; int32_t *E_idx; float *D_nb; KnnInit init; int sel_rows; };
+
+template <typename SP, bool PROF = false, bool IMG = false, bool KNN = false>
+__global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, unsigned long long *prof = nullptr, KnnFuseArgs kf = KnnFuseArgs{}) {
     unsigned long long t_last = 0;
     auto mark = [&](int k) {
         if (PROF && tm_bid() == 0 && tm_tid() == 0) {
@@ -779,6 +794,17 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
 
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin, cur = 0;
+    if constexpr (KNN) {
+#if TM_FEAT_DMA
+        __shared__ unsigned s_selk[64][2];
+        if (tm_bid() == 0 && tid == 0 && kf.init.status_zero) *kf.init.status_zero = 0;     // (as knn_kernel: nothing in this launch ORs into it)
+        if (wu == 0)
+            for (int r = tr.begin; r < tr.end; r += tr.step)
+                knn_residue<4>(nullptr, s_selk, a.X, kf.mask, kf.offsets, kf.N, kf.max_len, kf.K, kf.E_idx, kf.D_nb, nullptr, kf.init, kf.sel_rows, r, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the row is in L2 before any wavefront of this workgroup asks for it
+        __syncthreads();
+#endif
+    }
     if (i < tr.end) {
 #if TM_FEAT_DMA
         if (wu == 7) {
@@ -1017,8 +1043,16 @@ int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N,
     return tm_check_launch("knn_topk");
 }
 
+// kf != nullptr: the k-NN rows are computed inside the launch (featurize_fusable says when that form exists)
+bool featurize_fusable(const tmpnn_weights *w, int64_t T) {
+    if (tm_matmul_mode() != TM_MM_F16X2 || T <= 0 || T > (int64_t)tm_num_cus() || !TM_FEAT_DMA) return false;
+    for (int b = 0; b < 4; ++b) if (!tm_find_wimg(w->edge_w + 16 + 128 * b)) return false;
+    return tm_find_wimg(w->We_w) != nullptr;
+}
+
 int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx, const int32_t *cenc,
-                     const int32_t *E_idx, const float *D_nb, int64_t T, float *h_E, float *E_opt, hipStream_t st) {
+                     const int32_t *E_idx, const float *D_nb, int64_t T, float *h_E, float *E_opt, hipStream_t st,
+                     const KnnFuse *knn) {
     FeatArgs a;
     a.edge_w = w->edge_w; a.pos_table = w->pos_table; a.pos_w = w->pos_w; a.pos_b = w->pos_b; a.ln_w = w->norm_edges_w; a.ln_b = w->norm_edges_b;
     a.We_w = w->We_w; a.We_b = w->We_b; a.X = X; a.ridx = ridx; a.cenc = cenc; a.E_idx = E_idx; a.D_nb = D_nb;
@@ -1054,6 +1088,14 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
         return tm_check_launch("edge_featurize");
     }
 #endif
+    if (knn) {                                                   // small launch: k-NN + featurizer in one (the caller asked featurize_fusable)
+        if (!(tm_matmul_mode() == TM_MM_F16X2 && img && T <= cap)) { tm_prof_end(st); return tm_set_error(TMPNN_E_INVALID, "featurize: fused k-NN form not available for this launch"); }
+        static const bool sel_rows = TM_DBG_FLAG("TMPNN_KNN_SEL", true);
+        KnnFuseArgs kf{knn->mask, knn->offsets, knn->N, knn->max_len, knn->K, knn->E_idx, knn->D_nb, knn->init, sel_rows ? 1 : 0};
+        featurize_split_kernel<SplitH2, false, true, true><<<(int)T, 512, 0, st>>>(a, nullptr, kf);
+        tm_prof_end(st);
+        return tm_check_launch("knn_featurize_fused");
+    }
     if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
         if (img) featurize_split_kernel<SplitH2, false, true><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);
         else featurize_split_kernel<SplitH2><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a);

@@ -65,8 +65,12 @@ int launch_knn(const float *X, const float *mask, const int32_t *offsets, int N,
                int32_t *E_idx, float *D_nb, int32_t *status, hipStream_t st, KnnInit init = KnnInit{nullptr, nullptr, nullptr, nullptr});
 int launch_centrality(const float *X, const float *mask, const int32_t *offsets, int N, int64_t T, float radius,
                       int32_t *out, hipStream_t st);
+// small launches: the k-NN rows computed inside the featurizer launch (E_idx / D_nb are then OUTPUTS of it)
+struct KnnFuse { const float *mask; const int32_t *offsets; int N, max_len, K; int32_t *E_idx; float *D_nb; KnnInit init; };
+bool featurize_fusable(const tmpnn_weights *w, int64_t T);
 int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx, const int32_t *cenc,
-                     const int32_t *E_idx, const float *D_nb, int64_t T, float *h_E, float *E_opt, hipStream_t st);
+                     const int32_t *E_idx, const float *D_nb, int64_t T, float *h_E, float *E_opt, hipStream_t st,
+                     const KnnFuse *knn = nullptr);
 int launch_gather_rows(const float *nodes, const void *idx, int idx64, int64_t n_rows, int64_t rows_per_batch,
                        int64_t nodes_per_batch, int C, float *out, hipStream_t st);
 int launch_gather_edges(const float *edges, const int64_t *idx, int B, int N, int K, int C, float *out, hipStream_t st);

@@ -1,5 +1,5 @@
-"""debug: the fused small-launch form (edge update of layer l + message pass of the next layer in ONE launch, edge_msg_fused_kernel)
-against the two-launch path, bit for bit: a single L=256 protein, L=64, L=30 (< K: empty neighbour slots), a ragged batch of
+"""debug: the fused small-launch forms (k-NN inside the featurizer launch; edge update of layer l + message pass of the next layer in
+ONE launch, edge_msg_fused_kernel) against the separate launches, bit for bit — neighbour lists included: a single L=256 protein, L=64, L=30 (< K: empty neighbour slots), a ragged batch of
 three with masked residues, in f16x2. The switch lives in the debug variant of the library only.  python tools/dbg_fused.py (GPU box)"""
 import os, subprocess, sys
 import numpy as np
@@ -25,7 +25,7 @@ if len(sys.argv) > 1:
         X[mask == 0] = 0
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         ridx = np.concatenate([np.arange(L) for L in lens]).astype(np.int32)
-        r = eng.ssm_forward(X, S, mask, ridx, np.ones(T, np.int32), off, want_hidden=True, want_log_probs=True)
+        r = eng.ssm_forward(X, S, mask, ridx, np.ones(T, np.int32), off, want_hidden=True, want_log_probs=True, want_E_idx=True)
         for k, v in r.items():
             out[f"{k}{case}"] = v.cpu().numpy()
     np.savez(sys.argv[1], **out)
