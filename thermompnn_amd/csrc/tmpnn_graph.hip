@@ -1088,8 +1088,14 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
         return tm_check_launch("edge_featurize");
     }
 #endif
+    if (knn && !(tm_matmul_mode() == TM_MM_F16X2 && split_ok && img && T <= cap)) {
+        // (only reachable in the debug library, whose switches can take the image / split form away after featurize_fusable said yes)
+        tm_prof_end(st);
+        const int rc = launch_knn(X, knn->mask, knn->offsets, knn->N, T, knn->max_len, knn->K, knn->E_idx, knn->D_nb, nullptr, st, knn->init);
+        if (rc != TMPNN_OK) return rc;
+        return launch_featurize(w, X, ridx, cenc, E_idx, D_nb, T, h_E, E_opt, st, nullptr);
+    }
     if (knn) {                                                   // small launch: k-NN + featurizer in one (the caller asked featurize_fusable)
-        if (!(tm_matmul_mode() == TM_MM_F16X2 && img && T <= cap)) { tm_prof_end(st); return tm_set_error(TMPNN_E_INVALID, "featurize: fused k-NN form not available for this launch"); }
         static const bool sel_rows = TM_DBG_FLAG("TMPNN_KNN_SEL", true);
         KnnFuseArgs kf{knn->mask, knn->offsets, knn->N, knn->max_len, knn->K, knn->E_idx, knn->D_nb, knn->init, sel_rows ? 1 : 0};
         featurize_split_kernel<SplitH2, false, true, true><<<(int)T, 512, 0, st>>>(a, nullptr, kf);
