@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import TmpnnError, check
+from ._lib import check
 
 
 def usable_cpus() -> int:

@@ -19,13 +19,11 @@ from __future__ import annotations
 
 import argparse
 import csv
-import os
 from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
 
-from . import native_pdb
 from .datasets import ALPHABET
 
 AA20 = ALPHABET[:-1]

@@ -15,7 +15,6 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 def worker(precision):
     import numpy as np
-    import torch
     from conftest import load_golden, oracle_trace_f64, weights_for_case
     from test_gpu_parity import align, oracle_trace, packed_inputs
     from thermompnn_amd.engine import Engine
