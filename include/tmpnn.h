@@ -196,7 +196,7 @@ int tmpnn_ddg_head_generic(const float *const *hidden, int n_final, const float 
 
 /* ---- the fused path ------------------------------------------------------------------------------
  * Everything TransferModel.forward does on the device for a ragged batch of N proteins
- * (transfer_model.py:75-121 + protein_mpnn_utils.py:1222-1277), one call, ~30 launches on `stream`.
+ * (transfer_model.py:75-121 + protein_mpnn_utils.py:1222-1277), one call, 18 launches on `stream` (14 when every workgroup has at most one residue tile).
  * Outputs (each may be NULL except ddg): ddg [T,21]; hidden_opt [3,T,128] = decoder states 1..3
  * (the reference returns them reversed, :1277); log_probs_opt [T,21]; E_idx_opt [T,48] global rows.
  * status_opt (device int32, may be NULL) is zeroed on the stream and then receives TMPNN_STATUS_* bits. */

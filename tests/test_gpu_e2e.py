@@ -264,3 +264,37 @@ def test_pipeline_propagates_a_failing_consumer_and_stays_usable(tmp_path, engin
     assert seen[:2] == [0, 1] and len(engine._staging_pool) == 3
     n, stats = ssm_scan.scan_to_file(engine, paths, ["A"] * len(paths), str(tmp_path / "after.npz"), chunk_files=3)
     assert stats.chunks >= 4 and n == np.load(tmp_path / "after.npz")["ddg"].shape[0]
+
+
+def test_native_host_example_matches_python_pipeline(tmp_path, engine, synthetic_weights):
+    """examples/scan_native.cpp — a host that binds libtmpnn.so WITHOUT Python or torch (HIP runtime API for memory and one
+    stream; weights from the flat file of weights.export_raw) — writes the same bytes as the Python pipeline: the C-ABI is
+    the whole product, torch is plumbing. Also with files split over several chunks and in another precision."""
+    import subprocess
+    from thermompnn_amd import build, ssm_scan, weights
+    exe = os.path.join(os.path.dirname(build.HERE), "examples", "scan_native")
+    if not os.path.exists(exe):
+        build.build_native_example()
+    raw = str(tmp_path / "w.raw")
+    weights.export_raw(synthetic_weights, raw)
+    paths = _pdb_set(tmp_path, n=11, seed=3)
+    ref = str(tmp_path / "py.csv")
+    n, _ = ssm_scan.scan_to_file(engine, paths, ["A"] * len(paths), ref)
+    for extra in ([], ["--chunk_files", "4", "--threads", "3"]):
+        out = str(tmp_path / "native.csv")
+        r = subprocess.run([exe, raw, out] + extra + paths, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.startswith(f"{n} rows, ")
+        assert open(out, "rb").read() == open(ref, "rb").read()
+    # another precision goes through the same entry points (tmpnn_weights_create_p): equal to the engine at that precision
+    from thermompnn_amd.engine import Engine
+    eng32 = Engine(synthetic_weights, "cuda:0", 48, precision="fp32")
+    ssm_scan.scan_to_file(eng32, paths[:4], ["A"] * 4, ref)
+    r = subprocess.run([exe, raw, str(tmp_path / "n32.csv"), "--precision", "fp32"] + paths[:4], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(str(tmp_path / "n32.csv"), "rb").read() == open(ref, "rb").read()
+    # errors come back through tmpnn_last_error: a missing file, a weight file that is not one
+    r = subprocess.run([exe, raw, str(tmp_path / "x.csv"), str(tmp_path / "missing.pdb")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "missing.pdb" in r.stderr
+    r = subprocess.run([exe, paths[0], str(tmp_path / "x.csv"), paths[0]], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "TMPNNRAW" in r.stderr

@@ -639,3 +639,29 @@ def test_native_csv_streams_a_very_long_protein_in_blocks(tmp_path):
     assert w.rows == len(rows) and w.bytes > (64 << 20)
     import filecmp
     assert filecmp.cmp(str(tmp_path / "py.csv"), str(tmp_path / "nat.csv"), shallow=False)
+
+
+def test_raw_weight_file_and_native_example_build(tmp_path, synthetic_weights):
+    """weights.export_raw: the canonical tensor order, every element, as a host without Python reads it
+    (examples/scan_native.cpp); the example compiles against include/tmpnn.h + the HIP runtime API and links libtmpnn.so."""
+    import struct
+    import subprocess
+    from thermompnn_amd import _lib, build, weights
+    raw = tmp_path / "w.raw"
+    nbytes = weights.export_raw(synthetic_weights, str(raw))
+    blob = raw.read_bytes()
+    assert len(blob) == nbytes and blob[:8] == weights.RAW_MAGIC and struct.unpack_from("<i", blob, 8)[0] == _lib.N_TENSORS
+    lib, pos = _lib.load(), 12
+    for i, name in enumerate(_lib.tensor_names()):
+        numel = struct.unpack_from("<q", blob, pos)[0]
+        assert numel == lib.tmpnn_tensor_numel(i)
+        key = name if i >= _lib.N_MPNN_TENSORS else "prot_mpnn." + name
+        np.testing.assert_array_equal(np.frombuffer(blob, "<f4", numel, pos + 8), synthetic_weights[key].numpy().ravel())
+        pos += 8 + 4 * numel
+    assert pos == len(blob)
+    mpnn_only = {k: v for k, v in synthetic_weights.items() if k.startswith("prot_mpnn.")}
+    weights.export_raw(mpnn_only, str(tmp_path / "m.raw"))
+    assert struct.unpack_from("<i", (tmp_path / "m.raw").read_bytes(), 8)[0] == _lib.N_MPNN_TENSORS
+    exe = build.build_native_example(str(tmp_path / "scan_native"))      # its rpath is relative to examples/: name the library's directory
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60, env=dict(os.environ, LD_LIBRARY_PATH=build.HERE))
+    assert r.returncode == 1 and "usage: scan_native" in r.stderr

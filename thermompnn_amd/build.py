@@ -101,6 +101,27 @@ def build_pdb_sanitizer_driver(out: str | None = None) -> str:
     return out
 
 
+def build_native_example(out: str | None = None) -> str:
+    """examples/scan_native.cpp: a host without Python (PDB files -> CSV through the C-ABI + the HIP runtime API only).
+    Plain host C++ (g++); the ROCm root is taken from where hipcc lives."""
+    repo = os.path.dirname(HERE)
+    out = out or os.path.join(repo, "examples", "scan_native")
+    if not os.path.exists(LIB):
+        build_library()
+    rocm = os.path.dirname(os.path.dirname(os.path.realpath(_hipcc())))
+    gxx = shutil.which("g++")
+    if not gxx:
+        raise RuntimeError("g++ not found: examples/scan_native cannot be built on this machine")
+    cmd = [gxx, "-std=c++17", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(repo, "include"),
+           "-I", os.path.join(rocm, "include"), os.path.join(repo, "examples", "scan_native.cpp"), "-L", HERE, "-ltmpnn",
+           "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-pthread", "-Wl,-rpath,$ORIGIN/../thermompnn_amd",
+           "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building examples/scan_native failed:\n" + r.stdout)
+    return out
+
+
 if __name__ == "__main__":
     # python -m thermompnn_amd.build [--force] [--variant NAME -DFLAG ...]  (variant -> thermompnn_amd/libtmpnn_NAME.so)
     if "--pdb-sanitizer-driver" in sys.argv:
@@ -114,3 +135,4 @@ if __name__ == "__main__":
     else:
         print(build_library(force="--force" in sys.argv, verbose=True))
         print(build_debug_library(force="--force" in sys.argv, verbose=True))
+        print(build_native_example())

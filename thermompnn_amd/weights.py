@@ -273,3 +273,56 @@ def load_thermompnn_checkpoint(path, allow_pickle: bool = None):
     else:
         raise KeyError(f"{path}: not a checkpoint dictionary")
     return out
+
+
+RAW_MAGIC = b"TMPNNRAW"
+
+
+def export_raw(state_dict, path) -> int:
+    """The weight set as a flat file a host WITHOUT Python can read (examples/scan_native.cpp): ``RAW_MAGIC``, int32 tensor
+    count, then per tensor — in the library's canonical order, ``tmpnn_tensor_name(i)`` — int64 element count + little-endian
+    fp32 data. Accepts a TransferModel state dict (``prot_mpnn.*`` + head: 130 tensors) or a bare ProteinMPNN one (118).
+    -> bytes written."""
+    import struct
+    from . import _lib
+    names = _lib.tensor_names()
+    sd = dict(state_dict)
+    with_head = all(n in sd for n in names[_lib.N_MPNN_TENSORS:])
+    n = _lib.N_TENSORS if with_head else _lib.N_MPNN_TENSORS
+    lib = _lib.load()
+    total = 0
+    with open(path, "wb") as fh:
+        total += fh.write(RAW_MAGIC + struct.pack("<i", n))
+        for i, name in enumerate(names[:n]):
+            key = name if i >= _lib.N_MPNN_TENSORS else ("prot_mpnn." + name if ("prot_mpnn." + name) in sd else name)
+            if key not in sd:
+                raise KeyError(f"state dict lacks {key!r}")
+            a = np.ascontiguousarray(sd[key].detach().cpu().numpy().astype("<f4"))
+            if a.size != lib.tmpnn_tensor_numel(i):
+                raise ValueError(f"{key}: {a.size} elements, the engine expects {lib.tmpnn_tensor_numel(i)}")
+            total += fh.write(struct.pack("<q", a.size))
+            total += fh.write(a.tobytes())
+    return total
+
+
+def _main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="checkpoint -> flat fp32 weight file for hosts that bind libtmpnn.so without Python")
+    ap.add_argument("out")
+    ap.add_argument("--model_path", default="", help="a TransferModelPL checkpoint (thermoMPNN_default.pt)")
+    ap.add_argument("--vanilla_path", default="", help="the ProteinMPNN checkpoint (v_48_020.pt) the transfer model was trained on; "
+                    "needed when the Lightning checkpoint does not carry prot_mpnn.*")
+    ap.add_argument("--synthetic_weights", type=int, default=None, help="seed of a synthetic weight set instead of files")
+    a = ap.parse_args(argv)
+    if a.synthetic_weights is not None:
+        sd = synthetic_state_dict(a.synthetic_weights)
+    else:
+        sd = load_thermompnn_checkpoint(a.model_path)
+        if a.vanilla_path and not any(k.startswith("prot_mpnn.") for k in sd):
+            for k, v in load_vanilla_checkpoint(a.vanilla_path)[1].items():
+                sd["prot_mpnn." + k] = v
+    print(f"{a.out}: {export_raw(sd, a.out)} bytes")
+
+
+if __name__ == "__main__":
+    _main()
