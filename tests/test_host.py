@@ -665,3 +665,14 @@ def test_raw_weight_file_and_native_example_build(tmp_path, synthetic_weights):
     exe = build.build_native_example(str(tmp_path / "scan_native"))      # its rpath is relative to examples/: name the library's directory
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60, env=dict(os.environ, LD_LIBRARY_PATH=build.HERE))
     assert r.returncode == 1 and "usage: scan_native" in r.stderr
+
+
+def test_cpu_budget_is_shared_between_the_ranks_of_a_host(monkeypatch):
+    from thermompnn_amd import pipeline
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    host = pipeline.usable_cpus()
+    assert host == pipeline.usable_cpus(per_rank=False) >= 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert pipeline.usable_cpus() == max(1, host // 4) and pipeline.usable_cpus(per_rank=False) == host
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "not a number")
+    assert pipeline.usable_cpus() == host

@@ -33,8 +33,10 @@ from . import _lib
 from ._lib import check
 
 
-def usable_cpus() -> int:
-    """Logical CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota."""
+def usable_cpus(per_rank: bool = True) -> int:
+    """Logical CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota and — one process per
+    GPU under a launcher that exports LOCAL_WORLD_SIZE (torchrun) — divided among the ranks sharing this host, so that eight
+    pipelines do not each start a thread per CPU (``per_rank=False``: the host's figure)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -47,6 +49,11 @@ def usable_cpus() -> int:
             if q > 0:
                 n = min(n, max(1, int(q / per)))
         except (OSError, ValueError):
+            pass
+    if per_rank:
+        try:
+            n = max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or 1)))
+        except ValueError:
             pass
     return n
 
