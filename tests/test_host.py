@@ -676,3 +676,38 @@ def test_cpu_budget_is_shared_between_the_ranks_of_a_host(monkeypatch):
     assert pipeline.usable_cpus() == max(1, host // 4) and pipeline.usable_cpus(per_rank=False) == host
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "not a number")
     assert pipeline.usable_cpus() == host
+
+
+def test_native_host_entry_points_turn_exceptions_into_error_codes(tmp_path):
+    """A C++ exception must not cross the C-ABI (tmpnn_host_guard.hpp): with the address space capped, the CSV writer's
+    per-protein buffer (57 MB for L = 1700) cannot be allocated -> TMPNN_E_WORKSPACE ("out of host memory") on the caller's
+    thread, the process lives, and with several worker threads the in-order commit ticket of a failed protein is handed on
+    (no deadlock); the same handle then writes a small protein normally."""
+    import subprocess
+    import sys
+    from thermompnn_amd import build
+    code = r'''
+import ctypes as C, resource, sys
+lib = C.CDLL(sys.argv[1])
+lib.tmpnn_last_error.restype = C.c_char_p
+h = C.c_void_p()
+assert lib.tmpnn_csv_open(sys.argv[2].encode(), 0, C.byref(h)) == 0
+def write(L, n, threads):
+    tab = (C.c_float * (n * L * 21))()
+    off = (C.c_int32 * (n + 1))(*[i * L for i in range(n + 1)])
+    seqs = (C.c_char_p * n)(*[b"A" * L] * n)
+    names = (C.c_char_p * n)(*[b"p%d" % i for i in range(n)])
+    return lib.tmpnn_csv_write_ssm(h, tab, 21, off, n, seqs, names, None, b"M", b"D", None, None, 0, threads)
+vm = [int(l.split()[1]) for l in open("/proc/self/status") if l.startswith("VmSize")][0] * 1024
+resource.setrlimit(resource.RLIMIT_AS, (vm + (40 << 20), vm + (40 << 20)))
+for threads in (1, 4):
+    rc = write(1700, 6, threads)
+    msg = lib.tmpnn_last_error().decode()
+    assert rc == -4 and "out of host memory" in msg, (rc, msg)
+assert write(30, 3, 4) == 0, lib.tmpnn_last_error()
+rows, nbytes = C.c_int64(), C.c_int64()
+assert lib.tmpnn_csv_close(h, C.byref(rows), C.byref(nbytes)) == 0 and rows.value == 3 * 30 * 19
+print("ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code, build.LIB, str(tmp_path / "x.csv")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr[-1500:])

@@ -21,13 +21,14 @@
 #include <atomic>
 #include <charconv>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/tmpnn.h"
-int tm_set_error(int code, const char *fmt, ...);
+#include "tmpnn_host_guard.hpp"
 
 namespace {
 
@@ -127,15 +128,17 @@ extern "C" int tmpnn_csv_open(const char *path, int schema, tmpnn_csv_t **out) {
     if (fd < 0) return tm_set_error(TMPNN_E_INVALID, "csv_open: cannot create %s: %s", path, strerror(errno));
     const char *hdr = schema == 0 ? ",WT Seq,Model,Dataset,ddG_pred,position,wildtype,mutation,neighbors,best_AA,pdb\n"
                                   : ",Model,Dataset,ddG_pred,position,wildtype,mutation,pdb,chain\n";
-    tmpnn_csv *c = new tmpnn_csv();
-    c->fd = fd; c->schema = schema; c->path = path;
-    if (!write_all_at(fd, hdr, strlen(hdr), 0)) {
-        close(fd); delete c;
-        return tm_set_error(TMPNN_E_INVALID, "csv_open: write to %s failed: %s", path, strerror(errno));
-    }
-    c->bytes = (int64_t)strlen(hdr);
-    *out = c;
-    return TMPNN_OK;
+    const int rc = tm_host_guard("csv_open", [&]() -> int {
+        std::unique_ptr<tmpnn_csv> c(new tmpnn_csv());
+        c->fd = fd; c->schema = schema; c->path = path;
+        if (!write_all_at(fd, hdr, strlen(hdr), 0))
+            return tm_set_error(TMPNN_E_INVALID, "csv_open: write to %s failed: %s", path, strerror(errno));
+        c->bytes = (int64_t)strlen(hdr);
+        *out = c.release();
+        return TMPNN_OK;
+    });
+    if (rc != TMPNN_OK) close(fd);
+    return rc;
 }
 
 extern "C" int tmpnn_csv_close(tmpnn_csv_t *c, int64_t *rows_out, int64_t *bytes_out) {
@@ -164,6 +167,7 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
                                    int flags, int n_threads) {
     if (!c || !offsets || n < 0 || ld < 20 || (n > 0 && (!table || !seqs || !names)))
         return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: bad argument");
+    return tm_host_guard("csv_write_ssm", [&]() -> int {
     const bool pick = flags & TMPNN_CSV_PICK_BEST, cys = flags & TMPNN_CSV_INCLUDE_CYS;
     const int schema = c->schema;
     // running index of every protein's first row
@@ -178,15 +182,18 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
         first[i + 1] = first[i] + npos * (pick ? 1 : (cys ? 20 : 19));
     }
     const std::string f_model = csv_field(model), f_chain = csv_field(chain);
-    std::atomic<int> next(0);
+    std::atomic<int> next(0), write_errno(0);
     std::atomic<bool> failed(false);
     std::mutex mu;
     std::condition_variable cv;
     int commit = 0;                       // next protein allowed to take its file offset
     int64_t off = c->bytes;
+    auto write_failed = [&]() { int z = 0; write_errno.compare_exchange_strong(z, errno); failed = true; };
     auto work = [&]() {
         std::vector<char> buf;
         for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+          bool ticket_taken = false, ticket_returned = false;   // the others wait for protein i's ticket: it is handed on even if this protein throws
+          try {
             const char *seq = seqs[i];
             const int32_t L = offsets[i + 1] - offsets[i];
             const float *tab = table + (size_t)offsets[i] * ld;
@@ -257,41 +264,51 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
                     at = off;
                     off += (int64_t)len;
                     ++commit;
+                    ticket_taken = ticket_returned = true;
                 }
                 cv.notify_all();
-                if (len && !write_all_at(c->fd, buf.data(), len, at)) failed = true;
+                if (len && !write_all_at(c->fd, buf.data(), len, at)) write_failed();
             } else {
                 const int32_t step = (int32_t)std::max<size_t>(1, kBlock / (rows_per_pos * per_row));
                 buf.resize((size_t)step * rows_per_pos * per_row + 64);
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return commit == i; });
+                    ticket_taken = true;
                 }
                 int64_t row = first[i], at = off;                  // (this thread owns the tail of the file until it bumps `commit`)
                 for (int32_t p0 = 0; p0 < L; p0 += step) {
                     size_t len = 0;
                     row = format(p0, std::min<int32_t>(L, p0 + step), row, &len);
-                    if (len && !write_all_at(c->fd, buf.data(), len, at)) failed = true;
+                    if (len && !write_all_at(c->fd, buf.data(), len, at)) write_failed();
                     at += (int64_t)len;
                 }
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     off = at;
                     ++commit;
+                    ticket_returned = true;
                 }
                 cv.notify_all();
             }
+          } catch (...) {
+            if (!ticket_returned) {
+                std::unique_lock<std::mutex> lk(mu);
+                if (!ticket_taken) cv.wait(lk, [&] { return commit == i; });
+                ++commit;
+                lk.unlock();
+                cv.notify_all();
+            }
+            throw;                                              // tm_run_pool keeps the first one for the caller's thread
+          }
         }
     };
-    n_threads = std::max(1, std::min(n_threads, std::max(n, 1)));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-    if (failed) return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: write to %s failed: %s", c->path.c_str(), strerror(errno));
+    tm_run_pool(std::max(1, std::min(n_threads, std::max(n, 1))), work);
+    if (failed) return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: write to %s failed: %s", c->path.c_str(), strerror(write_errno.load()));
     c->rows = first[n];
     c->bytes = off;
     return TMPNN_OK;
+    });
 }
 
 // An explicit mutation list (BASELINE config 4; ssm_scan --mutations): triples [m, 3] int64 HOST of (protein, 0-based
@@ -301,6 +318,7 @@ extern "C" int tmpnn_csv_write_listed(tmpnn_csv_t *c, const float *table, int ld
                                       const char *model, const char *dataset, const int64_t *triples, int64_t m) {
     if (!c || c->schema != 0 || !offsets || n < 0 || ld < 20 || m < 0 || (m > 0 && (!table || !seqs || !names || !triples)))
         return tm_set_error(TMPNN_E_INVALID, "csv_write_listed: bad argument");
+    return tm_host_guard("csv_write_listed", [&]() -> int {
     const std::string mid = std::string(",") + csv_field(model) + "," + csv_field(dataset) + ",";
     std::vector<char> buf;
     buf.reserve(1 << 20);
@@ -343,6 +361,7 @@ extern "C" int tmpnn_csv_write_listed(tmpnn_csv_t *c, const float *table, int ld
     c->rows = row;
     c->bytes = at;
     return TMPNN_OK;
+    });
 }
 
 // repr(float(x)) as a C string (what the writer puts in the ddG_pred cell); exported so the host tests can pin the number

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -29,6 +30,7 @@
 // also builds with plain g++ under -fsanitize=address,undefined into the fuzz driver of tests/native/pdb_fuzz_driver.cpp
 // (python -m thermompnn_amd.build --pdb-sanitizer-driver).
 #include "../../include/tmpnn.h"
+#include "tmpnn_host_guard.hpp"
 int tm_set_error(int code, const char *fmt, ...);
 
 namespace {
@@ -284,7 +286,8 @@ static int parse_one(const char *path, const char *chains, tmpnn_pdb **out, std:
         for (char c = 'a'; c <= 'z'; ++c) order.push_back(c);
         for (char c = '0'; c <= '9'; ++c) order.push_back(c);
     }
-    tmpnn_pdb *pd = new tmpnn_pdb();
+    std::unique_ptr<tmpnn_pdb> holder(new tmpnn_pdb());      // released to the caller at the end; freed if anything below throws
+    tmpnn_pdb *pd = holder.get();
     size_t rows = 0;
     for (unsigned char ch : order)
         if (acc[ch].any) rows += std::max<size_t>(acc[ch].res.size(), (size_t)(acc[ch].hi - acc[ch].lo + 1));
@@ -326,16 +329,19 @@ static int parse_one(const char *path, const char *chains, tmpnn_pdb **out, std:
         ++cnum;
         ++pd->n_chains;
     }
-    *out = pd;
+    *out = holder.release();
     return TMPNN_OK;
 }
 
 extern "C" int tmpnn_pdb_parse(const char *path, const char *chains, tmpnn_pdb_t **out) {
     if (!path || !out) return tm_set_error(TMPNN_E_INVALID, "pdb_parse: null argument");
-    std::string err;
-    int rc = parse_one(path, chains, out, &err);
-    if (rc != TMPNN_OK) return tm_set_error(rc, "pdb_parse: %s", err.c_str());
-    return TMPNN_OK;
+    *out = nullptr;
+    return tm_host_guard("pdb_parse", [&]() -> int {
+        std::string err;
+        int rc = parse_one(path, chains, out, &err);
+        if (rc != TMPNN_OK) return tm_set_error(rc, "pdb_parse: %s", err.c_str());
+        return TMPNN_OK;
+    });
 }
 
 extern "C" int tmpnn_pdb_parse_batch(const char *const *paths, const char *const *chains, int n, int n_threads,
@@ -344,26 +350,24 @@ extern "C" int tmpnn_pdb_parse_batch(const char *const *paths, const char *const
     for (int i = 0; i < n; ++i) outs[i] = nullptr;
     if (n_threads < 1) n_threads = 1;
     n_threads = std::min(n_threads, std::max(n, 1));
-    std::atomic<int> next(0), failed(-1);
-    std::vector<std::string> errs(n);
-    auto work = [&]() {
-        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-            if (parse_one(paths[i], chains ? chains[i] : nullptr, &outs[i], &errs[i]) != TMPNN_OK) {
-                int exp = -1;
-                failed.compare_exchange_strong(exp, i);
+    const int rc = tm_host_guard("pdb_parse_batch", [&]() -> int {
+        std::atomic<int> next(0), failed(-1);
+        std::vector<std::string> errs(n);
+        tm_run_pool(n_threads, [&]() {
+            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+                if (parse_one(paths[i], chains ? chains[i] : nullptr, &outs[i], &errs[i]) != TMPNN_OK) {
+                    int exp = -1;
+                    failed.compare_exchange_strong(exp, i);
+                }
             }
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-    const int f = failed.load();
-    if (f >= 0) {
+        });
+        const int f = failed.load();
+        if (f >= 0) return tm_set_error(TMPNN_E_INVALID, "pdb_parse_batch: %s", errs[f].c_str());
+        return TMPNN_OK;
+    });
+    if (rc != TMPNN_OK)                       // a failed file or an exception (out of memory) in any worker: nothing is handed out
         for (int i = 0; i < n; ++i) { delete outs[i]; outs[i] = nullptr; }
-        return tm_set_error(TMPNN_E_INVALID, "pdb_parse_batch: %s", errs[f].c_str());
-    }
-    return TMPNN_OK;
+    return rc;
 }
 
 extern "C" int64_t tmpnn_pdb_length(const tmpnn_pdb_t *p) { return p ? (int64_t)p->S.size() : -1; }
@@ -410,19 +414,16 @@ extern "C" int tmpnn_pdb_pack_batch(tmpnn_pdb_t *const *handles, int n, int n_th
     }
     if (tot > capacity)
         return tm_set_error(TMPNN_E_WORKSPACE, "pdb_pack_batch: %lld residues, buffers hold %lld", (long long)tot, (long long)capacity);
-    std::atomic<int> next(0);
-    auto work = [&]() {
-        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-            const size_t o = (size_t)offsets[i];
-            tmpnn_pdb_fill(handles[i], X ? X + o * 12 : nullptr, S ? S + o : nullptr, mask ? mask + o : nullptr,
-                           residue_idx ? residue_idx + o : nullptr, chain_enc ? chain_enc + o : nullptr, nullptr,
-                           ca_mask ? ca_mask + o : nullptr);
-        }
-    };
-    n_threads = std::max(1, std::min(n_threads, n));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-    return TMPNN_OK;
+    return tm_host_guard("pdb_pack_batch", [&]() -> int {
+        std::atomic<int> next(0);
+        tm_run_pool(std::max(1, std::min(n_threads, n)), [&]() {
+            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+                const size_t o = (size_t)offsets[i];
+                tmpnn_pdb_fill(handles[i], X ? X + o * 12 : nullptr, S ? S + o : nullptr, mask ? mask + o : nullptr,
+                               residue_idx ? residue_idx + o : nullptr, chain_enc ? chain_enc + o : nullptr, nullptr,
+                               ca_mask ? ca_mask + o : nullptr);
+            }
+        });
+        return TMPNN_OK;
+    });
 }
