@@ -177,7 +177,7 @@ int main(int argc, char **argv) {
             names[i] = cells[i].c_str();
             seqs[i] = tmpnn_pdb_seq(pdb[i]);
         }
-        tm_ok(tmpnn_csv_write_ssm(csv, htab, 21, hoff, n, seqs.data(), names.data(), nullptr, "ThermoMPNN", "custom", nullptr, nullptr,
+        tm_ok(tmpnn_csv_write_ssm(csv, htab, 21, hoff, n, seqs.data(), nullptr, names.data(), nullptr, "ThermoMPNN", "custom", nullptr, nullptr,
                                   0, threads), "tmpnn_csv_write_ssm");
         for (tmpnn_pdb_t *p : pdb) tmpnn_pdb_free(p);
         for (void *p : {static_cast<void *>(dX), static_cast<void *>(dmask), static_cast<void *>(dtab), static_cast<void *>(dS),

@@ -197,7 +197,7 @@ int tmpnn_ddg_head_generic(const float *const *hidden, int n_final, const float 
 /* ---- the fused path ------------------------------------------------------------------------------
  * Everything TransferModel.forward does on the device for a ragged batch of N proteins
  * (transfer_model.py:75-121 + protein_mpnn_utils.py:1222-1277), one call, 18 launches on `stream` (14 when every workgroup has at most one residue tile).
- * Outputs (each may be NULL except ddg): ddg [T,21]; hidden_opt [3,T,128] = decoder states 1..3
+ * Outputs (each may be NULL; ddg needs a handle with the head tensors): ddg [T,21]; hidden_opt [3,T,128] = decoder states 1..3
  * (the reference returns them reversed, :1277); log_probs_opt [T,21]; E_idx_opt [T,48] global rows.
  * status_opt (device int32, may be NULL) is zeroed on the stream and then receives TMPNN_STATUS_* bits. */
 int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const int32_t *S, const float *mask,
@@ -246,9 +246,11 @@ enum { TMPNN_CSV_PICK_BEST = 1,      /* one row per position carrying best_AA = 
 int tmpnn_csv_open(const char *path, int schema, tmpnn_csv_t **out);          /* creates the file, writes the header */
 /* Appends the listing of n proteins (may be called once per chunk of a scan; the running index continues). offsets [n+1]
  * index `table`; seqs[i] (length = rows of protein i; '-' positions are skipped) ; names[i] = 'pdb' cell; neighbors (may be
- * NULL) [T] -> 'neighbors' cell; `datasets` (may be NULL) per-protein 'Dataset' cells instead of `dataset`; chain: schema 1. */
+ * NULL) [T] -> 'neighbors' cell; `datasets` (may be NULL) per-protein 'Dataset' cells instead of `dataset`; chain: schema 1;
+ * wt_cells (may be NULL) per-protein 'WT Seq' cells instead of seqs[i] — SSM.py:145-149 writes the DATASET's wild-type sequence
+ * (dataset.wt_seqs[key]) there, which need not be the parsed structure's. */
 int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
-                        const char *const *seqs, const char *const *names, const int32_t *neighbors, const char *model,
+                        const char *const *seqs, const char *const *wt_cells, const char *const *names, const int32_t *neighbors, const char *model,
                         const char *dataset, const char *const *datasets, const char *chain, int flags, int n_threads);
 /* Appends an explicit mutation list: triples [m,3] int64 (protein, 0-based position, amino-acid index < 20); schema 0. */
 int tmpnn_csv_write_listed(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,

@@ -79,7 +79,7 @@ int main(int argc, char **argv) {
             for (int flags = 0; flags < 4; ++flags) {
                 tmpnn_csv_t *c = nullptr;
                 if (tmpnn_csv_open("/dev/null", schema, &c) != TMPNN_OK) return 4;
-                if (tmpnn_csv_write_ssm(c, table.data(), 21, off.data(), n, seqs.data(), names.data(), flags & 1 ? nb.data() : nullptr, "Thermo,MPNN",
+                if (tmpnn_csv_write_ssm(c, table.data(), 21, off.data(), n, seqs.data(), flags & 2 ? names.data() : nullptr, names.data(), flags & 1 ? nb.data() : nullptr, "Thermo,MPNN",
                                         "a \"quoted\" set", nullptr, "A", flags, threads) != TMPNN_OK) return 4;
                 if (schema == 0 && tmpnn_csv_write_listed(c, table.data(), 21, off.data(), n, seqs.data(), names.data(), nb.data(), "m", "d",
                                                           tri.data(), (int64_t)tri.size() / 3) != TMPNN_OK) return 4;

@@ -298,3 +298,49 @@ def test_native_host_example_matches_python_pipeline(tmp_path, engine, synthetic
     assert r.returncode == 1 and "missing.pdb" in r.stderr
     r = subprocess.run([exe, paths[0], str(tmp_path / "x.csv"), paths[0]], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "TMPNNRAW" in r.stderr
+
+
+@pytest.mark.parametrize("pick_best,include_cys,centrality", [(False, False, False), (True, False, True), (False, True, True)])
+def test_scan_datasets_equals_the_reference_loop(tmp_path, pick_best, include_cys, centrality):
+    """ssm_scan.scan_datasets = the models x datasets driver loop of analysis/SSM.py:96-176 (one forward per protein, native
+    rows) against that loop written the reference's way — ``model(mut_pdb, mutations)`` per protein, one row dict per listed
+    mutant, 'WT Seq' from ``dataset.wt_seqs`` (NOT the parsed sequence: the sample CSV's SEQ column is a different string),
+    compute_centrality per protein — for ThermoMPNN and the ProteinMPNN baseline: byte-identical files."""
+    from thermompnn_amd import custom_inference, ssm_scan
+    from thermompnn_amd.datasets import ddgBenchDataset
+    from thermompnn_amd.ssm import mutation_objects
+    from thermompnn_amd.thermompnn_benchmarking import ProteinMPNNBaseline, compute_centrality
+    ds = ddgBenchDataset(None, GOLDEN, os.path.join(GOLDEN, "ddgbench_sample.csv"))
+    model = custom_inference.load_model(None, None, 0)
+    models = {"ProteinMPNN": ProteinMPNNBaseline(model.cfg, version="v_48_020.pt").eval().cuda(), "ThermoMPNN": model}
+    files = ssm_scan.scan_datasets(models, {"sample": ds}, pick_best=pick_best, include_cys=include_cys, centrality=centrality,
+                                   out_dir=str(tmp_path))
+    assert [os.path.basename(f) for f in files] == ["ProteinMPNN_sample_SSM_preds.csv", "ThermoMPNN_sample_SSM_preds.csv"]
+    for (name, m), f in zip(models.items(), files):
+        rows = []
+        for mut_pdb, _ in ds:
+            p = mut_pdb[0]
+            muts = mutation_objects(p)
+            with torch.no_grad():
+                pred, _ = m(mut_pdb, muts)
+            table = np.zeros((len(p["seq"]), 21), np.float32)
+            live = [(mu, o) for mu, o in zip(muts, pred) if mu is not None]
+            vals = torch.cat([o["ddG"].reshape(1) for _, o in live]).cpu().numpy()
+            for (mu, _), v in zip(live, vals):
+                table[mu.position, "ACDEFGHIKLMNPQRSTVWY".index(mu.mutation)] = v
+            nb = None
+            if centrality:
+                ck = [c for c in p.keys() if "coords" in c][0]
+                nb = compute_centrality(p[ck], basis_atom="CA", backup_atom="C", chain=ck[-1], radius=10.0).cpu().numpy()
+            r = ssm_scan.rows_for_protein(p, table, nb, name, "sample", pick_best, include_cys)
+            for x in r:
+                x["WT Seq"] = ds.wt_seqs[p["name"]]
+            rows += r
+        ref = str(tmp_path / "ref.csv")
+        ssm_scan.write_csv(rows, ref)
+        assert len(rows) > 100 and open(f, "rb").read() == open(ref, "rb").read(), name
+    # the compat module exposes the same function under the reference's module name
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(GOLDEN))
+    spec = importlib.util.spec_from_file_location("_compat_SSM", os.path.join(repo, "compat", "SSM.py"))
+    assert "scan_datasets" in open(spec.origin).read()

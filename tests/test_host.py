@@ -697,7 +697,7 @@ def write(L, n, threads):
     off = (C.c_int32 * (n + 1))(*[i * L for i in range(n + 1)])
     seqs = (C.c_char_p * n)(*[b"A" * L] * n)
     names = (C.c_char_p * n)(*[b"p%d" % i for i in range(n)])
-    return lib.tmpnn_csv_write_ssm(h, tab, 21, off, n, seqs, names, None, b"M", b"D", None, None, 0, threads)
+    return lib.tmpnn_csv_write_ssm(h, tab, 21, off, n, seqs, None, names, None, b"M", b"D", None, None, 0, threads)
 vm = [int(l.split()[1]) for l in open("/proc/self/status") if l.startswith("VmSize")][0] * 1024
 resource.setrlimit(resource.RLIMIT_AS, (vm + (40 << 20), vm + (40 << 20)))
 for threads in (1, 4):

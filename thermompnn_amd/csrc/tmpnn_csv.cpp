@@ -162,7 +162,7 @@ extern "C" int tmpnn_csv_close(tmpnn_csv_t *c, int64_t *rows_out, int64_t *bytes
 //   INCLUDE_CYS (SSM.py:153-166). Both schemas honour the flags; the custom_inference layout is written with INCLUDE_CYS
 //   (that script lists all 20 mutants).
 extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
-                                   const char *const *seqs, const char *const *names, const int32_t *neighbors,
+                                   const char *const *seqs, const char *const *wt_cells, const char *const *names, const int32_t *neighbors,
                                    const char *model, const char *dataset, const char *const *datasets, const char *chain,
                                    int flags, int n_threads) {
     if (!c || !offsets || n < 0 || ld < 20 || (n > 0 && (!table || !seqs || !names)))
@@ -202,7 +202,7 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
             const std::string f_data = csv_field(datasets ? datasets[i] : dataset);
             // the cells between the running index and the ddG value, and after the per-row cells
             std::string head = ",";
-            if (schema == 0) { head += csv_field(seq); head += ","; }
+            if (schema == 0) { head += csv_field(wt_cells && wt_cells[i] ? wt_cells[i] : seq); head += ","; }
             head += f_model; head += ","; head += f_data; head += ",";
             const int64_t nrows = first[i + 1] - first[i];
             const size_t per_row = 20 + head.size() + 26 + 12 + 4 + 12 + 2 + f_name.size() + f_chain.size() + 4;

@@ -48,8 +48,9 @@ class CsvWriter:
     def write_ssm(self, table: np.ndarray, offsets: np.ndarray, seqs: Sequence, names: Sequence,
                   neighbors: Optional[np.ndarray] = None, model: str = "ThermoMPNN", dataset: str = "custom",
                   datasets: Optional[Sequence] = None, chain: str = "", pick_best: bool = False, include_cys: bool = False,
-                  n_threads: int = 0) -> None:
-        """table: host float32 [T, ld >= 20] (C-contiguous); offsets int32 [n+1]; seqs / names: str, bytes or char* addresses."""
+                  n_threads: int = 0, wt_cells: Optional[Sequence] = None) -> None:
+        """table: host float32 [T, ld >= 20] (C-contiguous); offsets int32 [n+1]; seqs / names: str, bytes or char* addresses;
+        wt_cells: per-protein 'WT Seq' cells when they are not the parsed sequences (a dataset's own wild-type strings)."""
         table = np.ascontiguousarray(table, dtype=np.float32)
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
         n = offsets.size - 1
@@ -57,8 +58,10 @@ class CsvWriter:
         nb = None if neighbors is None else np.ascontiguousarray(neighbors, dtype=np.int32)
         cs, cn = _cstrs(seqs), _cstrs(names)
         cd = _cstrs(datasets) if datasets is not None else None
+        cw = _cstrs(wt_cells) if wt_cells is not None else None
+        assert wt_cells is None or len(wt_cells) == n
         flags = (PICK_BEST if pick_best else 0) | (INCLUDE_CYS if include_cys else 0)
-        _lib.check(self.lib.tmpnn_csv_write_ssm(self.h, table.ctypes.data, table.shape[1], offsets.ctypes.data, n, cs, cn,
+        _lib.check(self.lib.tmpnn_csv_write_ssm(self.h, table.ctypes.data, table.shape[1], offsets.ctypes.data, n, cs, cw, cn,
                                                 None if nb is None else nb.ctypes.data, model.encode(), dataset.encode(), cd,
                                                 chain.encode(), flags, n_threads or min(16, os.cpu_count() or 1)),
                    "tmpnn_csv_write_ssm")

@@ -175,6 +175,53 @@ def scan_to_file(engine, paths: Sequence[str], chains: Sequence, out: str, model
     return w.rows, stats
 
 
+def scan_datasets(models: dict, datasets: dict, pick_best: bool = False, include_cys: bool = False, centrality: bool = False,
+                  out_dir: str = ".", max_batches: Optional[int] = None, n_threads: int = 0) -> List[str]:
+    """The driver loop of the reference's SSM script as a function (analysis/SSM.py:96-176): every model of ``models``
+    (``TransferModel``, ``ProteinMPNNBaseline`` — anything with ``ssm_table(pdb)``) over every dataset of ``datasets``
+    (``ddgBenchDataset``, ``FireProtDataset``, ... — iterables of ``(pdb, mutations)`` with a ``wt_seqs`` dictionary), one file
+    ``<model>_<dataset>_SSM_preds.csv`` per pair in ``out_dir`` with the reference's columns and quirks: 'WT Seq' is the
+    DATASET's wild-type string (``wt_seqs[name]``, ``name + '.pdb'`` for Megascale sets, :145-149), 'pdb' is the
+    character-set-stripped structure name (:133), ``--pick_best`` / ``--include_cys`` / ``--centrality`` as there. One forward
+    per protein instead of one ``model(pdb, mutations)`` call plus 20 L ``.item()`` syncs; rows by the native writer.
+    -> the files written."""
+    import os
+    from . import native_csv
+    from .thermompnn_benchmarking import compute_centrality
+    written = []
+    for name, model in models.items():
+        model = model.eval()
+        for dataset_name, dataset in datasets.items():
+            tables, seqs, cells, names, neigh = [], [], [], [], []
+            for i, (mut_pdb, _listed) in enumerate(dataset):
+                p = mut_pdb[0]
+                with torch.no_grad():
+                    tables.append(model.ssm_table(mut_pdb))
+                seqs.append(p["seq"])
+                key = p["name"] if "Megascale" not in dataset_name else p["name"] + ".pdb"
+                wt = dataset.wt_seqs[key]
+                cells.append("" if wt is None else str(wt))              # pandas writes a missing value as an empty cell
+                names.append(p["name"].strip(".pdb"))
+                if centrality:
+                    coord_chain = [c for c in p.keys() if "coords" in c][0]
+                    neigh.append(compute_centrality(p[coord_chain], basis_atom="CA", backup_atom="C", chain=coord_chain[-1],
+                                                    radius=10.0, device=tables[-1].device).to(torch.int32))
+                    if neigh[-1].numel() != tables[-1].shape[0]:      # the reference indexes the FIRST chain's counts by position (:131-134)
+                        raise ValueError(f"{p['name']}: --centrality needs single-chain dataset entries "
+                                         f"({neigh[-1].numel()} residues in chain {coord_chain[-1]}, {tables[-1].shape[0]} parsed)")
+                if max_batches is not None and i >= max_batches:
+                    break
+            path = os.path.join(out_dir, name + "_" + dataset_name + "_SSM_preds.csv")
+            lens = [int(t.shape[0]) for t in tables]
+            flat = torch.cat(tables).cpu().numpy() if tables else np.zeros((0, 21), np.float32)     # one D2H copy per dataset
+            nb = torch.cat(neigh).cpu().numpy() if centrality and neigh else None
+            with native_csv.CsvWriter(path, native_csv.SCHEMA_SSM) as w:
+                w.write_ssm(flat, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), seqs, names, neighbors=nb, model=name,
+                            dataset=dataset_name, pick_best=pick_best, include_cys=include_cys, n_threads=n_threads, wt_cells=cells)
+            written.append(path)
+    return written
+
+
 def _now() -> float:
     import time
     return time.perf_counter()

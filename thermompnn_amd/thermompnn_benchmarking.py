@@ -47,6 +47,15 @@ class ProteinMPNNBaseline(_EngineOwner):
         self.prot_mpnn = get_protein_mpnn(cfg, version=version)
         self.k_neighbors = self.prot_mpnn.k_neighbors
 
+    def ssm_table(self, pdb) -> torch.Tensor:
+        """[L, 21] on the model's device: entry [pos, a] = the ddG ``forward`` returns for a mutation to ALPHABET[a] at pos
+        (= -log p), the whole scan from the one forward the reference also runs (:47-53)."""
+        device = next(self.parameters()).device
+        feats = tied_featurize([pdb[0] if isinstance(pdb, (list, tuple)) else pdb], device, None, None, None, None, None, None, ca_only=False)
+        X, S, mask, chain_M, chain_enc, residue_idx = feats[0], feats[1], feats[2], feats[4], feats[5], feats[12]
+        *_, log_probs = self.prot_mpnn(X, S, mask, chain_M, residue_idx, chain_enc, None)
+        return -log_probs[0]
+
     def forward(self, pdb, mutations, tied_feat=True):
         device = next(self.parameters()).device
         feats = tied_featurize([pdb[0]], device, None, None, None, None, None, None, ca_only=False)

@@ -82,6 +82,27 @@ class TransferModel(_EngineOwner):
                                     conv_w=None if conv is None else conv.weight, conv_b=None if conv is None else conv.bias,
                                     want_z=True)
 
+    def ssm_table(self, pdb) -> torch.Tensor:
+        """The whole site-saturation table of one parsed structure in ONE forward: [L, 21] on the model's device, entry
+        [pos, a] = what ``forward(pdb, [Mutation(pos, seq[pos], ALPHABET[a])])`` returns as ddG (the batched form of the
+        per-mutation loop of analysis/SSM.py:105-126; ``subtract_mut=False`` models return the un-subtracted head output)."""
+        device = next(self.parameters()).device
+        feats = tied_featurize([pdb[0] if isinstance(pdb, (list, tuple)) else pdb], device, None, None, None, None, None, None, ca_only=False)
+        X, S, mask, chain_enc, residue_idx = feats[0], feats[1], feats[2], feats[5], feats[12]
+        eng = self.engine()
+        L = X.shape[1]
+        with torch.cuda.device(eng.device):
+            std = self.subtract_mut and not self.generic_head
+            res = eng.ssm_forward(X[0], S[0], mask[0], residue_idx[0], chain_enc[0], torch.tensor([0, L], dtype=torch.int32),
+                                  max_len=L, want_hidden=not std, want_ddg=not self.generic_head)
+            if std:
+                return res["ddg"]
+            if self.generic_head:
+                ddg, z = self._generic_tables(eng, res["hidden"], S[0])
+            else:
+                ddg, z = res["ddg"], eng.ddg_head(res["hidden"][2], res["hidden"][1], S[0], want_z=True)[1]
+            return ddg if self.subtract_mut else z * self.ddg_out.weight.view(()) + self.ddg_out.bias.view(())
+
     def forward(self, pdb, mutations, tied_feat=True):
         device = next(self.parameters()).device
         feats = tied_featurize([pdb[0]], device, None, None, None, None, None, None, ca_only=False)
