@@ -344,3 +344,46 @@ def test_scan_datasets_equals_the_reference_loop(tmp_path, pick_best, include_cy
     repo = os.path.dirname(os.path.dirname(GOLDEN))
     spec = importlib.util.spec_from_file_location("_compat_SSM", os.path.join(repo, "compat", "SSM.py"))
     assert "scan_datasets" in open(spec.origin).read()
+
+
+def test_keep_preds_loop_writes_the_reference_frame(tmp_path):
+    """run_prediction_keep_preds / evaluate_datasets = analysis/thermompnn_benchmarking.py:122-187, 242-253: the raw-prediction
+    CSV in the layout of the reference's frame (a listed mutation without a measurement keeps a row with only WT Seq / Model /
+    Dataset; a residue number the structure lacks is dropped by the dataset; 'pdb' stripped; neighbours only with --centrality),
+    values = the golden ddG tables, metrics = run_prediction_default's."""
+    import csv
+    from thermompnn_amd import custom_inference
+    from thermompnn_amd.datasets import ddgBenchDataset
+    from thermompnn_amd.thermompnn_benchmarking import compute_centrality, evaluate_datasets, run_prediction_default
+    from conftest import load_golden
+    TOL_DDG = 1e-4            # kcal/mol; BASELINE.json north_star
+    ds = ddgBenchDataset(None, GOLDEN, os.path.join(GOLDEN, "ddgbench_sample.csv"))
+    model = custom_inference.load_model(None, None, 0)
+    res = evaluate_datasets({"ThermoMPNN": model}, {"sample": ds}, keep_preds=True, centrality=True, out_dir=str(tmp_path))
+    want = run_prediction_default("ThermoMPNN", model, "sample", ds, [])
+    assert res == want and res[0]["n"] == 6
+    text = (tmp_path / "ThermoMPNN_sample_raw_preds.csv").read_text()
+    lines = text.split("\n")
+    assert lines[0] == ",WT Seq,Model,Dataset,ddG_true,ddG_pred,position,wildtype,mutation,neighbors,best_AA,pdb" and lines[-1] == ""
+    rows = list(csv.DictReader(text.splitlines()))
+    assert [r[""] for r in rows] == [str(i) for i in range(7)]                 # 8 listed, A999G has no residue in the structure
+    g = {"2OCJ": load_golden("2OCJ_A")["ddg"], "2OCJ_gap_chainA": load_golden("2OCJ_A_gap")["ddg"]}
+    seq_cell = ds.wt_seqs["2OCJ"]
+    nb = {}
+    for pdb, _ in ds:
+        ck = [c for c in pdb[0].keys() if "coords" in c][0]
+        nb[pdb[0]["name"]] = compute_centrality(pdb[0][ck], basis_atom="CA", backup_atom="C", chain=ck[-1], radius=10.0).cpu().tolist()
+    n_scored = 0
+    for r in rows:
+        assert r["Model"] == "ThermoMPNN" and r["Dataset"] == "sample" and r["WT Seq"] == seq_cell and r["best_AA"] == ""
+        if r["ddG_pred"] == "":                                                 # Q100E: listed without a measurement
+            assert all(r[c] == "" for c in ("ddG_true", "position", "wildtype", "mutation", "neighbors", "pdb"))
+            continue
+        n_scored += 1
+        pos, a = int(r["position"]), "ACDEFGHIKLMNPQRSTVWY".index(r["mutation"])
+        assert abs(float(r["ddG_pred"]) - g[r["pdb"]][pos, a]) <= TOL_DDG and r["ddG_pred"] == repr(float(r["ddG_pred"]))
+        assert int(r["neighbors"]) == nb[r["pdb"]][pos] and r["pdb"] in g
+    assert n_scored == 6 and [r["ddG_true"] for r in rows if r["ddG_true"]][:3] == ["1.5", "-0.699999988079071", "-2.25"]
+    met = (tmp_path / "ThermoMPNN_metrics.csv").read_text().split("\n")
+    assert met[0] == ",Model,Dataset,ddG r2,ddG mse,ddG rmse,ddG spearman,ddG pearson" and met[1].startswith("0,ThermoMPNN,sample,")
+    assert [float(x) for x in met[1].split(",")[3:]] == [res[0][f"ddG {k}"] for k in ("r2", "mse", "rmse", "spearman", "pearson")]

@@ -141,3 +141,85 @@ def run_prediction_batched(name, engine, dataset_name, dataset, results, group=N
         column[f"ddG {k}"] = met[k]
     results.append(column)
     return results
+
+
+KEEP_PREDS_COLUMNS = ["WT Seq", "Model", "Dataset", "ddG_true", "ddG_pred", "position", "wildtype", "mutation", "neighbors",
+                      "best_AA", "pdb"]
+
+
+def run_prediction_keep_preds(name, model, dataset_name, dataset, results, centrality: bool = False, out_dir: str = "."):
+    """The reference's evaluation loop that also saves the raw predictions (:122-187): metrics appended to ``results`` as
+    ``run_prediction_default`` does, and ``<name>_<dataset_name>_raw_preds.csv`` in the layout its pandas frame gets — the
+    unnamed running index, the KEEP_PREDS_COLUMNS, one row per LISTED mutation: a mutation without a measured ddG still gets
+    its row with only 'WT Seq' / 'Model' / 'Dataset' filled (:159-167), 'WT Seq' = ``dataset.wt_seqs[key]`` and left empty for
+    S669 sets (:166), 'pdb' character-set-stripped (:150), 'neighbors' only with ``centrality``, 'best_AA' always empty.
+    One forward per protein and ONE device-to-host copy of its predictions (the reference syncs twice per mutation)."""
+    import csv
+    import os
+    from .metrics import get_metrics
+    pred_all, true_all, rows = [], [], []
+    for pdb, mutations in dataset:
+        if not mutations:
+            continue
+        with torch.no_grad():
+            pred, _ = model(pdb, mutations)
+        p = pdb[0]
+        neighbors = None
+        if centrality:
+            coord_chain = [c for c in p.keys() if "coords" in c][0]
+            neighbors = compute_centrality(p[coord_chain], basis_atom="CA", backup_atom="C", chain=coord_chain[-1], radius=10.0,
+                                           device=next(model.parameters()).device).cpu().tolist()
+        measured = [(m, o) for m, o in zip(mutations, pred) if m is not None and o is not None and m.ddG is not None]
+        vals = iter(torch.cat([o["ddG"].reshape(1) for _, o in measured]).cpu().tolist() if measured else [])
+        for m, o in zip(mutations, pred):
+            if m is None:
+                continue
+            row = dict.fromkeys(KEEP_PREDS_COLUMNS, "")
+            if o is not None and m.ddG is not None:
+                v, t = next(vals), float(torch.as_tensor(m.ddG).reshape(-1)[0])
+                pred_all.append(v)
+                true_all.append(t)
+                row.update({"ddG_true": t, "ddG_pred": v, "position": m.position, "wildtype": m.wildtype, "mutation": m.mutation,
+                            "pdb": (m.pdb or "").strip(".pdb")})
+                if neighbors is not None:
+                    row["neighbors"] = int(neighbors[m.position])
+            row["Model"], row["Dataset"] = name, dataset_name
+            if "S669" not in dataset_name:
+                wt = dataset.wt_seqs[m.pdb if "Megascale" not in dataset_name else m.pdb + ".pdb"]
+                row["WT Seq"] = "" if wt is None else wt
+            rows.append(row)
+    met = get_metrics(pred_all, true_all)
+    column = {"Model": name, "Dataset": dataset_name}
+    for k in ("r2", "mse", "rmse", "spearman", "pearson"):
+        column[f"ddG {k}"] = met[k]
+    column["n"] = met["n"]
+    results.append(column)
+    with open(os.path.join(out_dir, name + "_" + dataset_name + "_raw_preds.csv"), "w", newline="") as fh:
+        w = csv.writer(fh, lineterminator="\n")
+        w.writerow([""] + KEEP_PREDS_COLUMNS)
+        for i, r in enumerate(rows):
+            w.writerow([i] + [r[c] for c in KEEP_PREDS_COLUMNS])
+    return results
+
+
+def evaluate_datasets(models: dict, datasets: dict, keep_preds: bool = False, centrality: bool = False, out_dir: str = "."):
+    """The driver loop of the reference's benchmarking script (:242-253): every model over every dataset, then
+    ``ThermoMPNN_metrics.csv`` (index, Model, Dataset, ddG r2 / mse / rmse / spearman / pearson) in ``out_dir``.
+    -> the list of metric rows (each also carries ``n``, the number of scored mutations)."""
+    import csv
+    import os
+    results = []
+    for name, model in models.items():
+        model = model.eval()
+        for dataset_name, dataset in datasets.items():
+            if keep_preds:
+                run_prediction_keep_preds(name, model, dataset_name, dataset, results, centrality=centrality, out_dir=out_dir)
+            else:
+                run_prediction_default(name, model, dataset_name, dataset, results)
+    cols = ["Model", "Dataset"] + [f"ddG {k}" for k in ("r2", "mse", "rmse", "spearman", "pearson")]
+    with open(os.path.join(out_dir, "ThermoMPNN_metrics.csv"), "w", newline="") as fh:
+        w = csv.writer(fh, lineterminator="\n")
+        w.writerow([""] + cols)
+        for i, r in enumerate(results):
+            w.writerow([i] + [("" if isinstance(r[c], float) and r[c] != r[c] else r[c]) for c in cols])
+    return results
