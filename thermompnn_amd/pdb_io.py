@@ -6,8 +6,7 @@ Own implementation: one pass over the file for all chains, vectorised packing.
 """
 from __future__ import annotations
 
-import itertools
-from typing import Dict, Iterable, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch

@@ -4,8 +4,6 @@ per-dataset evaluation loops run_prediction_default / run_prediction_keep_preds 
 thermompnn_amd.datasets, scored with thermompnn_amd.metrics (torchmetrics / pandas / tqdm are not needed)."""
 from __future__ import annotations
 
-import ctypes as C
-
 import numpy as np
 import torch
 

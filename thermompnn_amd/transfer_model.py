@@ -9,7 +9,6 @@ from __future__ import annotations
 import os
 
 import torch
-import torch.nn as nn
 
 from . import weights as _weights
 from .datasets import ALPHABET
