@@ -849,22 +849,27 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
 #endif
         __syncthreads();
     }
+    // mask of the residue in the planes: requested one iteration before it is used (gfx9 waits for loads in order — fetched at the
+    // top of its own iteration it cost a vmcnt(0) right behind GEMM 1)
+    float mi = i < tr.end ? a.mask[i] : 0.f;
     mark(-1);
     for (; i < tr.end; i += tr.step) {
         const int inext = i + tr.step;
         const int ipf = inext < tr.end ? inext : i;             // the last iteration prefetches its own tile again
-        const float mi = a.mask[i];
-        // neighbour list of the next residue: loaded first, its dependent mask gather issued behind GEMM 1, both
-        // published to LDS only after the epilogue — no wavefront ever sits on a global-load latency in front of its MFMAs
+        // neighbour list of the next residue: loaded first, its dependent mask gather REQUESTED behind GEMM 1 and USED behind the
+        // epilogue, both published to LDS just in front of the barrier — no wavefront sits on a global-load latency. (Round 5: with
+        // the product mask[ipf] * mask[nidx] formed inside the `tid < 48` branch hipcc waited for the gather right where it was
+        // issued: wavefront 0 sat out a whole L2 round trip per tile in front of its GELU, the other seven at the barrier.)
         int nidx = -1;
         if (tid < TM_TILE) nidx = (a.E_idx + (size_t)__builtin_amdgcn_readfirstlane(ipf) * TM_KS)[(unsigned)tid];
+        const float mi_nxt = (a.mask + __builtin_amdgcn_readfirstlane(ipf))[0];
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
         mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tE, w1, acc, lane);
         mark(0);
-        float nma = 0.f;
-        if (tid < TM_TILE && nidx >= 0) nma = DEC ? 1.f : a.mask[ipf] * a.mask[(unsigned)nidx];
+        float mk_j = 1.f;
+        if (!DEC && tid < TM_TILE) mk_j = a.mask[(unsigned)(nidx >= 0 ? nidx : ipf)];       // requested only; first use below
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             f4 v = acc[rb][0];
@@ -873,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         }
         if (tid < TM_TILE) {
             s_idx[cur ^ 1][tid] = nidx;
-            s_ma[cur ^ 1][tid] = nma;
+            s_ma[cur ^ 1][tid] = nidx >= 0 ? (DEC ? 1.f : mi_nxt * mk_j) : 0.f;
         }
         mark(1);
         __syncthreads();                                         // tE consumed; tA, s_idx/s_ma[next] complete
@@ -885,6 +890,8 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         // loads, that wait would also force the tile loads home after one GEMM phase instead of one full iteration (an HBM
         // round trip under load is longer than a phase: ablation showed only 0.02 of the 0.09 ms of e-tile streaming hidden).
         gather(ipf, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);                       // (hipcc hoisted the tile request above the gathers: the wait for the
+                                                                 //  gathers at the end of the iteration then drained it too — vmcnt(0))
 #if TM_ABL_NOLOAD
 #elif TM_MSG_PFD == 2
 #pragma unroll
@@ -936,6 +943,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         mark(5);
         mark(6);
         cur ^= 1;
+        mi = mi_nxt;
         __syncthreads();                                         // tA consumed (the next GEMM-1 epilogue rewrites it), tE complete
         mark(7);
     }
