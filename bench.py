@@ -133,11 +133,30 @@ def pmc_traffic(kernel, T):
     return None
 
 
-# Issue cycles per wavefront instruction on one SIMD (DESIGN.md "What the hardware taught us": MFMA and VALU of the two
-# wavefronts of a SIMD are issued from one port and serialise — hetero_probe / pingpong_probe): a wave64 VALU op 4 cycles
-# (packed fp32 measured 5.3, reported as the `packed_5p3` variant), transcendentals quarter rate, v_mfma_f32_16x16x32_{f16,bf16}
-# 16 (8 passes), v_mfma_f32_16x16x4_f32 32.
-ISSUE_CYCLES = {"valu": 4.0, "valu_packed": 4.0, "valu_trans": 16.0}
+# Issue cost of one wavefront instruction as ONE SIMD sees it with its two wavefronts issuing dense, independent streams
+# (tools/probe/valu_cost_probe.hip, round 5, cycles): plain two-operand VALU 2.5, v_fma_f32 2.7, everything VOP3 / converting / DPP
+# 3.6-3.7, packed fp32 3.76, transcendentals / v_permlane*_swap / v_fma_mix* 6.6. (One wavefront alone cannot issue faster than one
+# VALU instruction per 5.0-5.6 cycles whatever the class.) MFMA: v_mfma_f32_16x16x32_{f16,bf16} 16 cycles of the SIMD's matrix pipe
+# (16.3 measured, tools/probe/hetero_probe.hip), v_mfma_f32_16x16x4_f32 32.
+VALU_COST = {"v_add_f32": 2.5, "v_sub_f32": 2.5, "v_mul_f32": 2.5, "v_mov_b32": 2.5, "v_fma_f32": 2.7, "v_fmac_f32": 2.7, "v_fmamk_f32": 2.7,
+             "v_fmaak_f32": 2.7, "v_permlane16_swap_b32": 6.6, "v_permlane32_swap_b32": 6.6, "v_fma_mixlo_f16": 6.6, "v_fma_mixhi_f16": 6.6}
+VALU_COST_DEFAULT, VALU_COST_PACKED, VALU_COST_TRANS = 3.6, 3.76, 6.6
+# what the pure-VALU wavefront of tools/probe/hetero_probe.hip keeps of its rate beside a saturated matrix pipe (4.4 -> 7.5 cycles
+# per v_fma_f32, 5.3 -> 7.7 per v_pk_fma_f32: 59-69 %)
+HETERO_VALU_RATE = 0.64
+
+
+def valu_cost(op):
+    base = op[:-4] if op.endswith(("_e32", "_e64")) else op
+    if base in VALU_COST:
+        return VALU_COST[base]
+    if base.startswith("v_pk_"):
+        return VALU_COST_PACKED
+    if base.startswith(("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")):
+        return VALU_COST_TRANS
+    return VALU_COST_DEFAULT
+
+
 ISA_SYMBOLS = {   # bench kernel name -> the instantiation the bench batch launches (f16x2, images, 32-bit gather offsets)
     "enc_edge": "enc_edge8_rp_kernelI7SplitH2Lb0ELb1E", "enc_msg": "msg8_rp_kernelI7SplitH2Lb0ELb0ELb1E",
     "dec_msg": "msg8_rp_kernelI7SplitH2Lb1ELb0ELb1E"}
@@ -163,38 +182,57 @@ def isa_counts(kernel):
                 continue
             for name, e in d["kernels"].items():
                 if sym in name and "tile_loop" in e:
-                    return dict(e["tile_loop"], file=os.path.basename(f), symbol=name, vgprs=e.get("next_free_vgpr"), lds_bytes=e.get("lds_bytes"))
+                    return dict(e["tile_loop"], file=os.path.basename(f), symbol=name, vgprs=e.get("next_free_vgpr"), lds_bytes=e.get("lds_bytes"),
+                                valu_ops=e.get("tile_loop_valu_ops", {}))
         except Exception:
             continue
     return None
 
 
 def issue_roof(kernel, tiles, n_cus, clock_ghz, avg_ms, waves_per_simd=2):
-    """The THIRD roof: instruction issue. One tile (= one residue's 48 x 128 edge block) is one trip of the
-    persistent loop in each of the workgroup's 8 wavefronts, 2 per SIMD; a SIMD issues VALU and MFMA instructions of its
-    wavefronts one at a time, so t_issue = tiles per CU x waves per SIMD x sum(count x issue cycles) / measured shader clock.
-    What is NOT in it: barriers, LDS and memory latency, the s_waitcnt / s_nop the loop also contains."""
+    """The THIRD roof: instruction issue, as a BRACKET. One tile (= one residue's 48 x 128 edge block) is one
+    trip of the persistent loop in each of the workgroup's 8 wavefronts, 2 per SIMD. Per SIMD and tile the two wavefronts issue
+    t_valu = 2 x sum(count x cost of the opcode) cycles of VALU work and t_mfma = 2 x sum(MFMA x 16) cycles of matrix-pipe work
+    (static counts of the shipped code object, costs measured by tools/probe/valu_cost_probe.hip / hetero_probe.hip). The two pipes
+    are separate, so the bound lies between
+      t_overlap = max(t_valu, t_mfma)   (the streams of the two wavefronts overlap perfectly) and
+      t_serial  = t_valu + t_mfma       (they never do — what lock-step GEMM / epilogue phases between barriers amount to),
+    with t_hetero = t_mfma + max(0, t_valu - 0.64 t_mfma) in between: the overlap the hetero probe measured for a pure MFMA stream
+    beside a pure VALU stream (the VALU stream keeps 59-69 % of its rate). None of them contains barriers, LDS / memory latency,
+    s_waitcnt or s_nop. `frac_*` = that time / the measured launch."""
     c = isa_counts(kernel)
     if c is None or not clock_ghz:
         return None
     mf = {k[5:]: v for k, v in c.items() if k.startswith("mfma:")}
     cyc_mfma = sum(mfma_cycles(op) * n for op, n in mf.items())
-    cyc_valu = sum(ISSUE_CYCLES[k] * c.get(k, 0) for k in ISSUE_CYCLES)
-    per_wave = cyc_mfma + cyc_valu
+    ops = c.get("valu_ops") or {}
+    n_valu = c.get("valu", 0) + c.get("valu_packed", 0) + c.get("valu_trans", 0)
+    if ops and sum(ops.values()) == n_valu:
+        cyc_valu = sum(valu_cost(op) * n for op, n in ops.items())
+    else:       # a counts file without the opcode histogram: class costs
+        cyc_valu = VALU_COST_DEFAULT * c.get("valu", 0) + VALU_COST_PACKED * c.get("valu_packed", 0) + VALU_COST_TRANS * c.get("valu_trans", 0)
     tiles_per_cu = -(-tiles // n_cus)
-    t = tiles_per_cu * waves_per_simd * per_wave / (clock_ghz * 1e9)
-    t53 = tiles_per_cu * waves_per_simd * (per_wave + 1.3 * c.get("valu_packed", 0)) / (clock_ghz * 1e9)
-    return {"t_issue_us": t * 1e6, "frac": t / (avg_ms * 1e-3), "frac_packed_5p3": t53 / (avg_ms * 1e-3),
-            "cycles_per_wavefront_tile": per_wave, "mfma_cycles": cyc_mfma, "valu_cycles": cyc_valu,
+    to_s = lambda cyc: tiles_per_cu * waves_per_simd * cyc / (clock_ghz * 1e9)
+    t_valu, t_mfma = to_s(cyc_valu), to_s(cyc_mfma)
+    t_serial, t_overlap = t_valu + t_mfma, max(t_valu, t_mfma)
+    t_hetero = t_mfma + max(0.0, t_valu - HETERO_VALU_RATE * t_mfma)
+    t_meas = avg_ms * 1e-3
+    return {"t_serial_us": t_serial * 1e6, "t_hetero_us": t_hetero * 1e6, "t_overlap_us": t_overlap * 1e6,
+            "frac_serial": t_serial / t_meas, "frac_hetero": t_hetero / t_meas, "frac_overlap": t_overlap / t_meas,
+            "t_valu_us": t_valu * 1e6, "t_mfma_us": t_mfma * 1e6,
+            "cycles_per_simd_tile": {"valu": waves_per_simd * cyc_valu, "mfma": waves_per_simd * cyc_mfma,
+                                     "measured": avg_ms * 1e-3 * clock_ghz * 1e9 / tiles_per_cu},
             "counts_per_wavefront_tile": {"mfma": sum(mf.values()), "valu": c.get("valu", 0), "valu_packed": c.get("valu_packed", 0),
                                           "valu_trans": c.get("valu_trans", 0), "salu": c.get("salu", 0), "lds": c.get("lds", 0),
                                           "vmem": c.get("vmem", 0), "barriers": c.get("barrier", 0), "waitcnt": c.get("waitcnt", 0)},
+            "mean_valu_cost_cycles": cyc_valu / n_valu if n_valu else None,
             "tiles_per_cu": tiles_per_cu, "waves_per_simd": waves_per_simd, "clock_GHz": clock_ghz,
-            "measured_cycles_per_tile": avg_ms * 1e-3 * clock_ghz * 1e9 / tiles_per_cu,
             "vgprs": c.get("vgprs"), "lds_bytes": c.get("lds_bytes"), "counts_from": c.get("file"), "symbol": c.get("symbol"),
-            "note": "static counts of the shipped code object's tile loop (tools/isa_counts.py); issue cycles: VALU 4 (packed fp32 "
-                    "measured 5.3 -> frac_packed_5p3), transcendental 16, 16x16x32 16-bit MFMA 16, fp32 16x16x4 MFMA 32; one issue port "
-                    "per SIMD shared by its 2 wavefronts (MFMA and VALU time add, DESIGN.md)"}
+            "note": "bracket of the instruction-issue bound: static counts of the shipped code object's tile loop (tools/isa_counts.py) x "
+                    "per-opcode issue cost with two wavefronts per SIMD (tools/probe/valu_cost_probe.hip: 2.5-3.8 cycles, transcendental / "
+                    "permlane swap 6.6), 16-bit 16x16x32 MFMA 16 cycles; serial = VALU + MFMA, overlap = max, hetero = the overlap "
+                    "tools/probe/hetero_probe.hip measured between a pure MFMA and a pure VALU wavefront. Barriers, LDS and memory "
+                    "latency, s_waitcnt / s_nop are in none of them"}
 
 
 def shader_clock_ghz(lib, device):
@@ -874,7 +912,8 @@ def main():
                     v["bound"], v["frac_of_binding_roof"] = rf["bound"], rf["frac"]
                     ir = issue_roof(k, T, n_cus, clock_ghz, v["avg_ms"]) if mode == "f16x2" and not strong else None
                     if ir:
-                        v["frac_of_issue_roof"], v["t_issue_us"] = ir["frac"], ir["t_issue_us"]
+                        v["frac_of_issue_serial"], v["frac_of_issue_overlap"] = ir["frac_serial"], ir["frac_overlap"]
+                        v["t_issue_serial_us"], v["t_issue_overlap_us"] = ir["t_serial_us"], ir["t_overlap_us"]
             dom = dom_name
             rf = kernel_roofs(dom, T, edges, kern[dom]["avg_ms"], mode)
             side = rf["hbm"] if rf["bound"] == "hbm" else rf["mfma"]
@@ -895,9 +934,10 @@ def main():
                          "operands once) / 8 TB/s; mfma = algorithmic fp32-class flops against " +
                          (f"{BF16_MFMA_PEAK_TFLOPS:.0f} / {terms} TFLOP/s (the kernel runs them as {terms}-term {mode} split products on the "
                           "16-bit matrix cores)" if terms else "the 157.3 TFLOP/s fp32 matrix pipe") +
-                         "; `bound` is the roof with the larger time, `frac` is against it; `issue` is the third roof — the instruction "
-                         "issue time of the shipped code object's tile loop at the measured clock — which is what paces this kernel "
-                         "in practice (its frac is the one to read for kernel quality)"),
+                         "; `bound` is the roof with the larger time, `frac` is against it; `issue` is the third roof as a bracket — the "
+                         "VALU and matrix-pipe time of the shipped code object's tile loop at the measured clock, serialised "
+                         "(frac_serial) or perfectly overlapped (frac_overlap); the kernel's lock-step GEMM / epilogue phases put it "
+                         "near the serial end"),
                 "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r*_pmc_traffic.json; null when no file was measured on these kernel sources)",
                 "timed_with": "hipEvent pairs on the launch stream around this kernel's launches inside the timed region"}
             result["kernels"] = kern

@@ -81,4 +81,6 @@ def test_committed_isa_counts_belong_to_the_committed_kernel_sources():
     assert c is not None, "profiles/r*_isa_counts.json is stale: run python tools/isa_counts.py"
     assert c["mfma:v_mfma_f32_16x16x32_f16"] == 108 and c["valu"] + c["valu_packed"] + c["valu_trans"] > 300
     ir = bench.issue_roof("enc_edge", 16384, 256, 2.3, 0.30)
-    assert 0.5 < ir["frac"] < 1.0 and ir["tiles_per_cu"] == 64 and ir["cycles_per_wavefront_tile"] == ir["mfma_cycles"] + ir["valu_cycles"]
+    assert ir["tiles_per_cu"] == 64 and 0.2 < ir["frac_overlap"] < ir["frac_hetero"] < ir["frac_serial"] < 1.0
+    assert abs(ir["t_serial_us"] - (ir["t_valu_us"] + ir["t_mfma_us"])) < 1e-9 and ir["t_overlap_us"] == max(ir["t_valu_us"], ir["t_mfma_us"])
+    assert 2.5 <= ir["mean_valu_cost_cycles"] <= 6.6        # priced per opcode (tools/probe/valu_cost_probe.hip)

@@ -41,11 +41,12 @@ def _linear_bf16_3term(x, w, b=None):
 
 
 def _kernel_gelu_coefficients():
-    """The exponent polynomial of the shipped GELU (tmpnn_common.h: gelu2, TM_GELU_FORM == 1), highest power first, parsed from
+    """The exponent polynomial of the shipped GELU (tmpnn_common.h: gelu2), highest power first, parsed from
     the kernel source so that the emulation below cannot drift from what the GPU runs."""
     import re
     src = open(os.path.join(os.path.dirname(HERE), "thermompnn_amd", "csrc", "tmpnn_common.h")).read()
-    blk = src[src.index("#if TM_GELU_FORM == 1"):src.index("#else", src.index("#if TM_GELU_FORM == 1"))]
+    a = src.index("__device__ __forceinline__ f2 gelu2(f2 x) {")
+    blk = src[src.index("f2 q = ", a):src.index("const f2 e = ", a) + 80]
     c = [float(x) for x in re.findall(r"(-?\d\.\d+e[+-]\d+)f", blk)]
     c = [c[0], c[2]] + c[4:]                 # the first fma lists each of its two constants twice ({c, c})
     assert len(c) == 7, c
@@ -53,7 +54,7 @@ def _kernel_gelu_coefficients():
 
 
 def _gelu_kernel_form(x):
-    """gelu2 as the f16x2 kernels run it (TM_GELU_NAN3, tmpnn_split.hip), in emulated fp32: t = min(|x|, 4 sqrt2); 6 Horner fmas;
+    """gelu2 as the f16x2 kernels run it (TM_GELU_NAN3: tmpnn_edge / _msg / _node.hip), in emulated fp32: t = min(|x|, 4 sqrt2); 6 Horner fmas;
     exp2; max(x, 0) - t h with the CLAMPED t (every step rounded to fp32)."""
     c = _kernel_gelu_coefficients()
     ax = x.abs()

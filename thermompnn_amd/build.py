@@ -14,7 +14,8 @@ LIB = os.path.join(HERE, "libtmpnn.so")
 # shipped library does not contain (its launchers never read the environment, allocate or synchronise). A/B tests, tools/dbg_*.py
 # and tools/phase_prof.py load it through TMPNN_LIB.
 DEBUG_LIB = os.path.join(HERE, "libtmpnn_debug.so")
-SOURCES = ["tmpnn_api.hip", "tmpnn_graph.hip", "tmpnn_layers.hip", "tmpnn_head.hip", "tmpnn_split.hip", "tmpnn_pdb.cpp", "tmpnn_csv.cpp"]
+SOURCES = ["tmpnn_api.hip", "tmpnn_graph.hip", "tmpnn_layers.hip", "tmpnn_head.hip", "tmpnn_split.hip", "tmpnn_edge.hip", "tmpnn_msg.hip",
+           "tmpnn_edge_msg.hip", "tmpnn_node.hip", "tmpnn_pdb.cpp", "tmpnn_csv.cpp"]
 HEADERS = ["tmpnn_common.h", "tmpnn_split.h", "tmpnn_internal.h", os.path.join("..", "..", "include", "tmpnn.h"),
            os.path.join("..", "..", "include", "tmpnn_debug.h"), "tmpnn_host_guard.hpp"]
 # -mcode-object-version=5: tm_nblk() / tm_bdim() (tmpnn_common.h) read gridDim / blockDim at fixed offsets of the v5
@@ -24,10 +25,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # kernels only (.hip): no sNaN-quieting "v_max x, x" in front of every v_min / v_max (the GELU clamps). Device code never
 # relies on NaNs (range checks test the exponent bits); the host-side PDB reader (.cpp) does and keeps IEEE semantics.
 DEVICE_FLAGS = ["-mno-amdgpu-ieee", "-fno-honor-nans"]
-# ... except the f16x2 per-edge / node kernels (tmpnn_split.hip): their GELU clamps are gfx950's NaN-PROPAGATING v_minimum3_f32 /
+# ... except the f16x2 per-edge / node kernels (tmpnn_edge / _msg / _edge_msg / _node.hip, and tmpnn_split.hip with the device self-test
+# of exactly this property): their GELU clamps are gfx950's NaN-PROPAGATING v_minimum3_f32 /
 # v_maximum3_f32 (IEEE-754-2019; no canonicalising op in front of them either), which hipcc emits from __builtin_elementwise_minimum /
 # maximum only in a translation unit that honours NaNs (under -fno-honor-nans they degrade to v_min / v_max). See gelu2, TM_GELU_NAN3.
-FILE_FLAGS = {"tmpnn_split.hip": ["-DTM_GELU_NAN3=1"]}
+NAN3_FILES = ("tmpnn_split.hip", "tmpnn_edge.hip", "tmpnn_msg.hip", "tmpnn_edge_msg.hip", "tmpnn_node.hip")
+FILE_FLAGS = {f: ["-DTM_GELU_NAN3=1"] for f in NAN3_FILES}
 
 
 def _hipcc() -> str:

@@ -130,41 +130,50 @@ __device__ __forceinline__ float gelu1(float x) {
 // Two values at a time: the Horner chain, the scalings and the final products run as packed fp32 ops
 // (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes-worth of fp32 per issue slot) — same arithmetic as gelu1.
 typedef float f2 __attribute__((ext_vector_type(2)));
-// gelu(x) = max(x, 0) - u h(u),  u = min(|x|, 4 sqrt2),  h(u) = 0.5 erfc(u / sqrt2) = exp2(u B(u) - 1): B = the degree-8 fit above
-// with the 1/sqrt2 folded into its coefficients (tools/fit_gelu.py; max abs error 2.4e-7 in emulated fp32, the rounding
-// floor of x Phi(x)). Per value: v_min (|x| as a source modifier), 9 Horner steps + 1 (packed two values at a time),
-// v_exp, v_max and one fma with a negated |x| source. The product uses |x| itself, not the clamped u: a NaN / inf input
-// must come out as NaN (v_min / v_max return their finite operand, so u and max(x, 0) alone would turn a poisoned
-// value into a finite one and hide an fp16 overflow of the f16x2 path); for 4 sqrt2 < |x| < 50 that costs < 4e-7.
-#ifndef TM_GELU_ASM
-#define TM_GELU_ASM 1
-#endif
+// gelu(x) = max(x, 0) - u h(u),  u = min(|x|, 4 sqrt2),  h(u) = 0.5 erfc(u / sqrt2) = exp2(P(u)) (tools/fit_gelu.py). Per value:
+// v_min (|x| as a source modifier), 6 Horner steps (packed two values at a time), v_exp, v_max and one fma.
 // One packed Horner step q <- q t + c, c broadcast from the low half of an SGPR pair. Written as inline asm because hipcc
 // splits about a third of these v_pk_fma_f32 back into two v_fma_f32 when they sit near MFMAs — sensible for an
 // MFMA-bound loop, but these kernels are VALU-issue-bound and a packed op costs the same ~4 cycles as a scalar one.
 // (Operands are VALU-produced values only, so no MFMA read hazard hides inside the asm.)
 __device__ __forceinline__ f2 pk_horner(f2 q, f2 t, float c) {
-#if TM_GELU_ASM
     f2 r;
     const unsigned long long cc = (unsigned long long)__float_as_uint(c);
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(r) : "v"(q), "v"(t), "s"(cc));
     return r;
-#else
-    return __builtin_elementwise_fma(q, t, f2{c, c});
-#endif
 }
-// TM_GELU_FORM: 1 (default) = exponent polynomial P of degree 6 with a free constant term, fitted to the error of gelu itself
-// (tools/fit_gelu.py: max abs error 2.8e-7 — the fp32 rounding floor of x Phi(x) is 2.4e-7) — 6 packed Horner steps;
-// 0 = round 1's degree-8 fit of the exponent with the constant pinned to -1 (2.4e-7, 10 steps): same accuracy, 4 more VALU
-// instructions per pair of values, and these kernels are paced by their VALU instruction COUNT.
-#ifndef TM_GELU_FORM
-#define TM_GELU_FORM 1
-#endif
+// The exponent polynomial P: degree 6 with a free constant term, fitted to the error of gelu itself (tools/fit_gelu.py: max abs error
+// 2.8e-7 — the fp32 rounding floor of x Phi(x) is 2.4e-7) — 6 packed Horner steps. (Rounds 1-2: a degree-8 fit of the exponent with
+// the constant pinned to -1, same accuracy, 4 more VALU instructions per pair of values.)
 #ifndef TM_GELU_NAN3
-#define TM_GELU_NAN3 0     // 1 (tmpnn_split.hip, built WITH NaN semantics: build.py FILE_FLAGS): NaN-propagating clamps, clamped-t tail
+#define TM_GELU_NAN3 0     // 1 (the f16x2 per-edge / node files, built WITH NaN semantics: build.py FILE_FLAGS): NaN-propagating clamps, clamped-t tail
+#endif
+// Timing-only ablations (tools/ablate.sh: ONE ingredient removed, results wrong by construction) exist in debug builds only — the
+// shipped library compiles exactly one form of every kernel: TM_ABL_NOGELU (GELU = identity), TM_ABL_NOSPLIT (high plane only),
+// TM_ABL_NOMFMA (tile GEMMs issue nothing), TM_ABL_NOLN (edge update without LayerNorm statistics), TM_ABL_NOLOAD (per-edge kernels
+// never fetch the next tile), TM_ABL_NOGAUSS (featurizer without Gaussians).
+#ifndef TMPNN_DEBUG_BUILD
+#if defined(TM_ABL_NOGELU) || defined(TM_ABL_NOSPLIT) || defined(TM_ABL_NOMFMA) || defined(TM_ABL_NOLN) || defined(TM_ABL_NOLOAD) || defined(TM_ABL_NOGAUSS)
+#error "TM_ABL_* timing ablations need -DTMPNN_DEBUG_BUILD (python -m thermompnn_amd.build --variant NAME -DTMPNN_DEBUG_BUILD -DTM_ABL_...)"
+#endif
 #endif
 #ifndef TM_ABL_NOGELU
 #define TM_ABL_NOGELU 0
+#endif
+#ifndef TM_ABL_NOSPLIT
+#define TM_ABL_NOSPLIT 0
+#endif
+#ifndef TM_ABL_NOMFMA
+#define TM_ABL_NOMFMA 0
+#endif
+#ifndef TM_ABL_NOLN
+#define TM_ABL_NOLN 0
+#endif
+#ifndef TM_ABL_NOLOAD
+#define TM_ABL_NOLOAD 0
+#endif
+#ifndef TM_ABL_NOGAUSS
+#define TM_ABL_NOGAUSS 0
 #endif
 __device__ __forceinline__ f2 gelu2(f2 x) {
 #if TM_ABL_NOGELU
@@ -175,24 +184,12 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
 #else
     const f2 t = f2{fminf(fabsf(x.x), 5.656854249f), fminf(fabsf(x.y), 5.656854249f)};
 #endif
-#if TM_GELU_FORM == 1
     f2 q = __builtin_elementwise_fma(f2{3.309543916e-05f, 3.309543916e-05f}, t, f2{-7.692427171e-04f, -7.692427171e-04f});
     q = pk_horner(q, t, 8.080792133e-03f);
     q = pk_horner(q, t, -5.341222090e-02f);
     q = pk_horner(q, t, -4.587708865e-01f);
     q = pk_horner(q, t, -1.151201730e+00f);
     const f2 e = pk_horner(q, t, -9.999930581e-01f);
-#else
-    f2 q = __builtin_elementwise_fma(f2{1.243920691e-07f, 1.243920691e-07f}, t, f2{-3.183690609e-06f, -3.183690609e-06f});
-    q = pk_horner(q, t, 3.204980433e-05f);
-    q = pk_horner(q, t, -1.323212435e-04f);
-    q = pk_horner(q, t, -2.864045193e-04f);
-    q = pk_horner(q, t, 7.258569310e-03f);
-    q = pk_horner(q, t, -5.261051294e-02f);
-    q = pk_horner(q, t, -4.591856045e-01f);
-    q = pk_horner(q, t, -1.151105393e+00f);
-    const f2 e = pk_horner(q, t, -1.0f);
-#endif
     // the library is built with -mno-amdgpu-ieee -fno-honor-nans: fminf / fmaxf are single v_min / v_max (no canonicalising
     // v_max x, x in front of each)
 #if TM_GELU_NAN3

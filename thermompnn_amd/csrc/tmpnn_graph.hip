@@ -548,9 +548,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : 1)) void featurize_kernel(F
 // fp32 output tile — are aliased on the dead RBF planes.
 // ------------------------------------------------------------------------------------------------
 #define RBFP_ROWB 1024
-#ifndef TM_ABL_NOGAUSS
-#define TM_ABL_NOGAUSS 0   // timing-only ablation: the Gaussians are not generated (GEMM 1 runs on stale planes)
-#endif
 #ifndef TM_FEAT_PF
 #define TM_FEAT_PF 1      // B-fragment prefetch distance of GEMM 1 (mma_tile_split): 1 = 0.500 ms with 38 spilled VGPRs (reloaded around the GEMM, not in it) against 0.524 at 0 (13 spilled), 0.527 at 2
 #endif

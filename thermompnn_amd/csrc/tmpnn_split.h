@@ -28,14 +28,16 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
-#ifndef TM_SPLIT_MIX
-#define TM_SPLIT_MIX 0     // 1: SplitH2::split2 through v_fma_mixlo/hi_f16 (same bits, 3 instead of 5 VALU ops per pair; measured: enc_edge -1 %, dec_msg +2 %, net nil — off)
-#endif
-#ifndef TM_ABL_NOSPLIT
-#define TM_ABL_NOSPLIT 0   // timing-only ablation: SplitH2 writes the high plane only (no residual, low plane = 0)
-#endif
-#ifndef TM_ABL_NOMFMA
-#define TM_ABL_NOMFMA 0    // timing-only ablation: the tile GEMMs issue no MFMA (and, with nothing to feed, no fragment reads)
+// Tunables of the kernels built on these cores (each measured, see docs/NOTEBOOK.md): B-fragment prefetch distances of the tile GEMMs
+// (steps ahead, see mma_tile_split), the node kernel's weight-image ring, the thread whose cycle counter the debug build's phase
+// timers read.
+#define TM_EDGE_PF 2        // edge update: 0.339 ms at 0, 0.329 at 1, 0.323 at 2, 0.326 at 3-4 (round 2)
+#define TM_MSG_PF 3         // message kernels
+#define TM_NODE_PF 3        // node update, tall tile
+#define TM_NODE_DEEP_D 3    // node update, one 16-row tile per workgroup: fragment images in flight ahead of the GEMM unit being computed
+#define TM_NODE_DEEP_PF 2   // ... its B-fragment prefetch distance (a 16-row GEMM has 4 steps; 3 would hold all four at once: 8 more VGPRs)
+#ifndef TM_PROF_TID
+#define TM_PROF_TID 0       // thread of workgroup 0 the TMPNN_*_PROF phase timers read (448 = wavefront 7, lowest issue priority)
 #endif
 #define SPLIT_PLANE_BYTES (TM_TILE * TM_H * 2)   // one 48 x 128 plane of 16-bit values: 12288 B
 
@@ -90,19 +92,9 @@ struct SplitH2 {
         p[1] = 0u;
         return;
 #endif
-#if TM_SPLIT_MIX
-        // l = fp16(x - h) per half in ONE mixed-precision fma each (f32 x, f16 h read in place, f16 result written into its
-        // half of the destination): 3 VALU ops per pair instead of 5 (two v_cvt_f32_f16, a packed subtract, a packed
-        // convert). Same bits — tools/probe/mix_split_check.hip compares the two forms on 4 M random pairs.
-        unsigned l;
-        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x.x), "v"(p[0]));
-        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x.y), "v"(p[0]));
-        p[1] = l;
-#else
         const f2 r = x - __builtin_convertvector(h, f2);                    // exact
         const h2 l = __builtin_convertvector(r, h2);
         p[1] = __builtin_bit_cast(unsigned, l);
-#endif
     }
     static __device__ __forceinline__ f2 join2(const unsigned (&p)[2]) {
         const f2 h = __builtin_convertvector(__builtin_bit_cast(h2, p[0]), f2);
@@ -378,3 +370,51 @@ __device__ __forceinline__ void row_stats_finish8d(const float *stat_row, int la
     const float m2 = allreduce8_dpp(__builtin_fmaf(16.f * d, d, p.y));
     rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(m2, 1.0f / 128.0f, 1e-5f));
 }
+
+// ------------------------------------------------------------------------------------------------
+// shared by the per-edge kernel files (tmpnn_edge.hip, tmpnn_msg.hip, tmpnn_edge_msg.hip, tmpnn_node.hip)
+// ------------------------------------------------------------------------------------------------
+// Weight fragment of wavefront wv from a pre-built image (WImg, tmpnn_internal.h): 8 coalesced 16-byte loads instead of the
+// 16-row fp32 gathers + on-the-fly split of load_wfrag_split. img == nullptr -> the gather path.
+template <typename SP>
+__device__ __forceinline__ void load_wfrag_auto(const char *img, const float *__restrict__ W, int ld, int wv, int lane,
+                                                WFragS<SP> (&wf)[4]) {
+    if (img != nullptr && SP::NP == 2) {
+        const char *p = img + (size_t)wv * 8192 + lane * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            wf[c].p[0] = *reinterpret_cast<const u4 *>(p + 2048 * c);
+            wf[c].p[1] = *reinterpret_cast<const u4 *>(p + 2048 * c + 1024);
+        }
+    } else {
+        load_wfrag_split<SP, 4>(W, ld, 16 * wv, 0, TM_H, wf, lane);
+    }
+}
+
+struct EdgeArgsB {
+    const float *W11e, *W12, *b12, *W13, *b13, *g3, *be3, *P;
+    float *hE;
+    const int32_t *E_idx;
+    int T;
+    const char *img11, *img12, *img13;      // fragment images of the three weights (f16x2 only) or null
+};
+
+struct MsgArgsB {
+    const float *W1e; int ld1;
+    const float *W2, *b2, *P;
+    const float *hE;
+    const int32_t *E_idx;
+    const float *mask;
+    float *Ssum, *cnt;
+    int T;
+    const char *img1, *img2;                // fragment images of W1e / W2 (f16x2 only) or null
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Timing-only ablations of the per-edge kernels and the featurizer (WRONG results, by construction): every variant removes one
-# ingredient so that its true cost in the pipeline shows up as a time difference in ONE gpurun call.
+# ingredient so that its true cost in the pipeline shows up as a time difference in ONE gpurun call. The ablations compile only
+# with -DTMPNN_DEBUG_BUILD (tmpnn_common.h refuses them otherwise): the shipped library holds one form of every kernel.
 #   tools/ablate.sh build      (here, no GPU needed)      -> thermompnn_amd/libtmpnn_abl_*.so
 #   tools/ablate.sh run        (on the GPU box)           -> gpurun_out/ablate.log
 # Round 3 (64 x L=256, f16x2; enc_edge / enc_msg / dec_msg / featurize in ms):
@@ -13,10 +14,10 @@ case "$1" in
 build)
   for v in "nogelu -DTM_ABL_NOGELU=1" "nosplit -DTM_ABL_NOSPLIT=1" "nomfma -DTM_ABL_NOMFMA=1" "noln -DTM_ABL_NOLN=1" "noload -DTM_ABL_NOLOAD=1"; do
     set -- $v; n=$1; shift
-    python -m thermompnn_amd.build --variant abl_$n "$@" --only=tmpnn_split.hip 2>&1 | tail -1 &
+    python -m thermompnn_amd.build --variant abl_$n -DTMPNN_DEBUG_BUILD "$@" --only=tmpnn_edge.hip --only=tmpnn_msg.hip 2>&1 | tail -1 &
   done
-  python -m thermompnn_amd.build --variant abl_fnomfma -DTM_ABL_NOMFMA=1 --only=tmpnn_graph.hip 2>&1 | tail -1 &
-  python -m thermompnn_amd.build --variant abl_fnogauss -DTM_ABL_NOGAUSS=1 -DTM_ABL_NOMFMA=1 --only=tmpnn_graph.hip 2>&1 | tail -1 &
+  python -m thermompnn_amd.build --variant abl_fnomfma -DTMPNN_DEBUG_BUILD -DTM_ABL_NOMFMA=1 --only=tmpnn_graph.hip 2>&1 | tail -1 &
+  python -m thermompnn_amd.build --variant abl_fnogauss -DTMPNN_DEBUG_BUILD -DTM_ABL_NOGAUSS=1 -DTM_ABL_NOMFMA=1 --only=tmpnn_graph.hip 2>&1 | tail -1 &
   wait ;;
 run)
   mkdir -p gpurun_out

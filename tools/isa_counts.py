@@ -5,7 +5,7 @@ Compiles every .hip of thermompnn_amd/csrc to gfx950 assembly with the flags of 
 (hipcc --offload-device-only -S), finds in each kernel the largest loop (the persistent tile loop: the backward branch whose
 span holds the most instructions) and counts what one wavefront issues per trip: MFMA by shape, VALU (packed, transcendental
 and the rest separately — they issue at different rates), SALU, LDS, vector memory, barriers / waits.
-    python tools/isa_counts.py [out.json]        (default profiles/r04_isa_counts.json; needs hipcc, no GPU)
+    python tools/isa_counts.py [out.json]        (default profiles/r05_isa_counts.json; needs hipcc, no GPU)
 The file is stamped with the hash of the kernel sources: bench.py ignores a file measured on other sources."""
 import json
 import os
@@ -100,6 +100,18 @@ def count(items):
     return c
 
 
+def valu_histogram(items):
+    """opcode -> count of the VALU instructions (the issue-roof bracket of bench.py prices them per opcode with the costs
+    tools/probe/valu_cost_probe.hip measured)."""
+    h = {}
+    for _, _, ins in items:
+        if ins:
+            op = ins.split()[0]
+            if classify(op).startswith("valu"):
+                h[op] = h.get(op, 0) + 1
+    return dict(sorted(h.items()))
+
+
 def demangle(names):
     try:
         r = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names) + "\n", capture_output=True, text=True, check=True)
@@ -109,7 +121,7 @@ def demangle(names):
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "profiles", "r04_isa_counts.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "profiles", "r05_isa_counts.json")
     import bench
     res = {"source_stamp": bench.kernel_source_stamp(), "flags": tm_build.FLAGS, "kernels": {}}
     with tempfile.TemporaryDirectory() as tmp:
@@ -137,6 +149,7 @@ def main():
                 entry = {"file": src, "whole_kernel": count(body), **meta.get(sym, {})}
                 if loop:
                     entry["tile_loop"] = count(body[loop[0]:loop[1] + 1])
+                    entry["tile_loop_valu_ops"] = valu_histogram(body[loop[0]:loop[1] + 1])
                     entry["tile_loop_instructions"] = loop[2]
                 res["kernels"][names[sym]] = entry
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
