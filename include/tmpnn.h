@@ -238,12 +238,20 @@ int tmpnn_pdb_pack_batch(tmpnn_pdb_t *const *handles, int n, int n_threads, int6
  * Replaces the cell-by-cell pandas frame + DataFrame.to_csv of analysis/SSM.py:102-176 (schema 0: ",WT Seq,Model,
  * Dataset,ddG_pred,position,wildtype,mutation,neighbors,best_AA,pdb") and analysis/custom_inference.py:64,94-111
  * (schema 1: ",Model,Dataset,ddG_pred,position,wildtype,mutation,pdb,chain"), byte for byte what pandas writes: '\n'
- * line ends, running index first, floats as repr(float(x)), empty cells for missing values, minimal quoting.
+ * line ends, running index first, floats as repr(float(x)), empty cells for missing values (a NaN ddG included), minimal
+ * quoting — pinned to files made by pandas itself (tests/golden/make_csv_golden.py).
  * HOST pointers; tables are the [T, ld] fp32 ddG tables of tmpnn_ssm_forward copied back (ld >= 20). */
 typedef struct tmpnn_csv tmpnn_csv_t;
-enum { TMPNN_CSV_PICK_BEST = 1,      /* one row per position carrying best_AA = argmin ddG (SSM.py:32-42,153-162) */
-       TMPNN_CSV_INCLUDE_CYS = 2 };  /* otherwise C is excluded from best_AA / rows mutating to C are dropped (:164-166) */
-int tmpnn_csv_open(const char *path, int schema, tmpnn_csv_t **out);          /* creates the file, writes the header */
+enum { TMPNN_CSV_PICK_BEST = 1,      /* one row per position carrying best_AA = argmin ddG (SSM.py:32-42,153-162); the schema-0
+                                      * frame then has one more column, ",dupe_detector" = pdb + str(position) (:161), never dropped */
+       TMPNN_CSV_INCLUDE_CYS = 2,    /* otherwise C is excluded from best_AA / rows mutating to C are dropped (:164-166) */
+       TMPNN_CSV_NO_HEADER = 4 };    /* tmpnn_csv_open_ex: a part file of a sharded scan — no header line */
+int tmpnn_csv_open(const char *path, int schema, tmpnn_csv_t **out);          /* creates the file, writes the header (of the first
+                                                                               * listing written: PICK_BEST adds its column) */
+/* The same with the header decided at once: flags = TMPNN_CSV_PICK_BEST (header with dupe_detector) | TMPNN_CSV_NO_HEADER. */
+int tmpnn_csv_open_ex(const char *path, int schema, int flags, tmpnn_csv_t **out);
+/* The header line of a schema (flags: TMPNN_CSV_PICK_BEST) into buf -> its length, NUL-terminated (cap > length). */
+int tmpnn_csv_header(int schema, int flags, char *buf, int cap);
 /* Appends the listing of n proteins (may be called once per chunk of a scan; the running index continues). offsets [n+1]
  * index `table`; seqs[i] (length = rows of protein i; '-' positions are skipped) ; names[i] = 'pdb' cell; neighbors (may be
  * NULL) [T] -> 'neighbors' cell; `datasets` (may be NULL) per-protein 'Dataset' cells instead of `dataset`; chain: schema 1;
@@ -252,6 +260,14 @@ int tmpnn_csv_open(const char *path, int schema, tmpnn_csv_t **out);          /*
 int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
                         const char *const *seqs, const char *const *wt_cells, const char *const *names, const int32_t *neighbors, const char *model,
                         const char *dataset, const char *const *datasets, const char *chain, int flags, int n_threads);
+/* One rank's share of a scan that N ranks write into ONE file (the loop of SSM.py:105-176 sharded over GPUs): first_rows (may be
+ * NULL) [n] = the running index of each protein's first row in the whole listing (every rank can compute them from the sequences
+ * alone), bytes_out (may be NULL) [n] <- bytes of text written per protein; the ranks exchange those, and each places its
+ * proteins' text at their offsets of the one output file (thermompnn_amd/dist.py: scan_files_to_csv). */
+int tmpnn_csv_write_ssm_ex(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
+                           const char *const *seqs, const char *const *wt_cells, const char *const *names, const int32_t *neighbors, const char *model,
+                           const char *dataset, const char *const *datasets, const char *chain, int flags, int n_threads,
+                           const int64_t *first_rows, int64_t *bytes_out);
 /* Appends an explicit mutation list: triples [m,3] int64 (protein, 0-based position, amino-acid index < 20); schema 0. */
 int tmpnn_csv_write_listed(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
                            const char *const *seqs, const char *const *names, const int32_t *neighbors, const char *model,

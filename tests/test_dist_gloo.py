@@ -186,3 +186,82 @@ def test_single_process_scan_needs_no_group():
     lengths = [7, 3, 9]
     tables = scan_sharded(lengths, lambda ids: torch.cat([fake_table(i, lengths[i]) for i in ids]))
     assert all(torch.equal(t, fake_table(i, L)) for i, (t, L) in enumerate(zip(tables, lengths)))
+
+
+# ---- the sharded result writer (round 5): every rank formats its shard, byte offsets are exchanged, ONE file comes out ----------
+def _seq_table(seq, with_neighbors):
+    """A deterministic stand-in for a protein's [L, 21] ddG table (and neighbour counts), a function of the sequence only."""
+    r = np.random.default_rng(sum(ord(c) * (k + 1) for k, c in enumerate(seq)))
+    t = r.normal(scale=2.0, size=(len(seq), 21)).astype(np.float32)
+    return t, (r.integers(0, 40, size=len(seq)).astype(np.int32) if with_neighbors else None)
+
+
+def _standin_pipeline(engine, paths, chains, sink, centrality=False, chunk_files=2, **_):
+    """What pipeline.scan_files does, without a GPU: parse (native, CPU), 'forward' = _seq_table, chunks handed to the sink in
+    file order."""
+    from thermompnn_amd import native_pdb, pipeline
+    pos, index = 0, 0
+    while pos < len(paths):
+        m = min(chunk_files, len(paths) - pos)
+        prots = native_pdb.parse_pdbs(list(paths[pos:pos + m]), list(chains[pos:pos + m]))
+        tabs = [_seq_table(p["seq"], centrality) for p in prots]
+        off = np.concatenate([[0], np.cumsum([len(p["seq"]) for p in prots])]).astype(np.int32)
+        sink(pipeline.Chunk(index=index, first=pos, n=m, T=int(off[-1]), offsets=off, table=np.concatenate([t for t, _ in tabs]),
+                            neighbors=np.concatenate([nb for _, nb in tabs]) if centrality else None,
+                            seq_ptrs=[p["seq"] for p in prots], names=[os.path.basename(x)[:-4] for x in paths[pos:pos + m]]))
+        pos += m
+        index += 1
+    return pipeline.ScanStats(files=len(paths))
+
+
+class _NoEngine:
+    K = 48
+
+
+def _csv_worker(rank, world, port, paths, out, pick, cen, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from thermompnn_amd.dist import scan_files_to_csv
+        rows, _ = scan_files_to_csv(_NoEngine(), paths, ["A"] * len(paths), out, "ThermoMPNN", "my set", pick_best=pick, include_cys=not pick,
+                                    centrality=cen, n_threads=2, run_pipeline=_standin_pipeline, chunk_files=2)
+        q.put((rank, rows, os.path.exists(f"{out}.part{rank}")))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_files,pick,cen", [(7, False, True), (7, True, False), (1, False, False)])
+def test_sharded_csv_is_byte_identical_to_the_one_writer_file(tmp_path, n_files, pick, cen):
+    """dist.scan_files_to_csv on two gloo ranks (a stand-in pipeline on CPU): the one output file equals what ONE writer makes of
+    the same tables in file order — running indices, --pick_best's dupe_detector column, neighbour counts — including the case
+    where a rank's shard is empty (one file, two ranks); the part files are gone afterwards."""
+    import shutil
+    from conftest import GOLDEN
+    from thermompnn_amd import native_csv, native_pdb
+    src = [os.path.join(GOLDEN, "2OCJ.pdb"), os.path.join(GOLDEN, "2OCJ_gap_chainA.pdb")]
+    paths = []
+    for k in range(n_files):
+        dst = str(tmp_path / f"prot{k}.pdb")
+        shutil.copy(src[k % 2], dst)
+        paths.append(dst)
+    out = str(tmp_path / "sharded.csv")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_csv_worker, args=(r, 2, port, paths, out, pick, cen, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    prots = native_pdb.parse_pdbs(paths, ["A"] * n_files)
+    tabs = [_seq_table(p["seq"], cen) for p in prots]
+    off = np.concatenate([[0], np.cumsum([len(p["seq"]) for p in prots])]).astype(np.int32)
+    with native_csv.CsvWriter(str(tmp_path / "one.csv")) as w:
+        w.write_ssm(np.concatenate([t for t, _ in tabs]), off, [p["seq"] for p in prots], [f"prot{k}".strip(".pdb") for k in range(n_files)],
+                    neighbors=np.concatenate([nb for _, nb in tabs]) if cen else None, dataset="my set", pick_best=pick,
+                    include_cys=not pick, n_threads=2)
+    want = (tmp_path / "one.csv").read_bytes()
+    assert (tmp_path / "sharded.csv").read_bytes() == want
+    assert all(rows == w.rows and not part_left for _, rows, part_left in results)

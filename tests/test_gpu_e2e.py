@@ -123,8 +123,9 @@ def test_custom_inference_fast_path_equals_the_reference_shaped_path(tmp_path):
 
 
 def test_sharded_file_scan_two_ranks_one_device(tmp_path):
-    """The many-PDB CLI under torchrun (2 ranks on cuda:0, gloo): every rank runs the pipeline on its LPT shard, one gather to
-    rank 0, same bytes as the single-process streaming run — CSV with post-processing and the binary tables."""
+    """The many-PDB CLI under torchrun (2 ranks on cuda:0, gloo): every rank runs the pipeline on its LPT shard; CSV: every rank
+    formats its shard and places its text in the one file (dist.scan_files_to_csv), binary: one gather to rank 0 — same bytes as
+    the single-process streaming run, CSV with post-processing and the binary tables."""
     import subprocess
     import sys
     from test_gpu_parity import _torchrun
@@ -144,6 +145,14 @@ def test_sharded_file_scan_two_ranks_one_device(tmp_path):
     a, b = np.load(one_npz), np.load(tmp_path / "two.npz")
     np.testing.assert_array_equal(a["ddg"], b["ddg"])
     assert list(a["names"]) == list(b["names"]) and list(a["offsets"]) == list(b["offsets"])
+    # the RCCL form of the binary path (tables stay on the device between the forwards and the gather), forced under gloo, with centrality
+    r = _torchrun(["-m", "thermompnn_amd.ssm_scan"] + paths + ["--synthetic_weights", "0", "--centrality", "--device_tables", "--chunk_files", "3",
+                                                            "--out", str(tmp_path / "dev.npz")], {"TMPNN_ONE_DEVICE": "1", "PYTHONPATH": repo})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    c = np.load(tmp_path / "dev.npz")
+    one_c = np.load(ssm_scan.main(paths + ["--synthetic_weights", "0", "--centrality", "--out", str(tmp_path / "one_c.npz")]))
+    np.testing.assert_array_equal(a["ddg"], c["ddg"])
+    np.testing.assert_array_equal(one_c["neighbors"], c["neighbors"])
     # a corrupt file fails BOTH ranks promptly (no rank may be left waiting in a collective)
     bad = tmp_path / "bad.pdb"
     bad.write_text("ATOM      1  N   ALA A   1      xx.000   0.000   0.000\n")

@@ -21,11 +21,13 @@ WORST = {}          # (precision, quantity) -> worst |hip - reference| / toleran
 
 
 def engine_for(g, precision=None):
-    """One engine per (weight set, precision) of the golden fixtures."""
+    """One engine per (weight set, precision) of the golden fixtures. No retry precision: an f16x2 forward that left the fp16 range
+    raises TmpnnRangeError instead of coming back as a silent bf16x3 rerun that would pass "as f16x2" (VERDICT r4 weak 1b); the
+    retry itself is covered by its own tests (test_range_overflow_is_detected_and_retried, test_gpu_e2e's pipeline rerun)."""
     from thermompnn_amd.engine import Engine
     key = (int(g["weight_seed"]), str(g["weight_style"]) if "weight_style" in g else "xavier", precision)
     if key not in _ENGINES:
-        _ENGINES[key] = Engine(weights_for_case(g), "cuda:0", 48, precision=precision)
+        _ENGINES[key] = Engine(weights_for_case(g), "cuda:0", 48, precision=precision, retry_precision=None)
     return _ENGINES[key]
 
 
@@ -77,7 +79,7 @@ def _dump_worst():
 def engine(synthetic_weights):
     from thermompnn_amd.engine import Engine
     assert torch.cuda.is_available(), "GPU tests need the MI355X box"
-    return Engine(synthetic_weights, "cuda:0", 48)
+    return Engine(synthetic_weights, "cuda:0", 48, retry_precision=None)      # (see engine_for: no silent reruns in parity tests)
 
 
 def oracle_trace(W, g, E_idx=None):

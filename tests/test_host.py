@@ -503,6 +503,53 @@ def test_native_csv_writer_equals_row_writer(tmp_path, pick, cys, use_nb):
     assert (tmp_path / "one.csv").read_bytes() == a
 
 
+@pytest.mark.parametrize("pick", [False, True])
+@pytest.mark.parametrize("cys", [False, True])
+@pytest.mark.parametrize("cen", [False, True])
+def test_csv_writers_equal_files_made_by_pandas(tmp_path, pick, cys, cen):
+    """Both writers against tests/golden/csv/*.csv — frames built cell by cell and written by REAL pandas exactly as the reference
+    does (tests/golden/make_csv_golden.py restates SSM.py:102-176 operation for operation): every flag combination, a gap, the
+    character-set strip of the name, a WT cell that needs quoting, exponent-form floats, a NaN (empty cell) and an inf, and the
+    ``dupe_detector`` column the reference's --pick_best frames carry."""
+    from thermompnn_amd import native_csv, ssm_scan
+    g = np.load(os.path.join(GOLDEN, "csv", "csv_inputs.npz"))
+    want = open(os.path.join(GOLDEN, "csv", f"ssm_pick{int(pick)}_cys{int(cys)}_cen{int(cen)}.csv"), "rb").read()
+    names, seqs, wts = [str(x) for x in g["names"]], [str(x) for x in g["seqs"]], [str(x) for x in g["wts"]]
+    off, table, nb = g["offsets"].astype(np.int32), g["table"], g["neighbors"]
+    rows = []
+    for i in range(len(seqs)):
+        rows += ssm_scan.rows_for_protein({"seq": seqs[i], "name": names[i], "wt": wts[i]}, table[off[i]:off[i + 1]],
+                                          nb[off[i]:off[i + 1]] if cen else None, "ThermoMPNN", "P53", pick, cys)
+    ssm_scan.write_csv(rows, str(tmp_path / "py.csv"), pick_best=pick)
+    assert (tmp_path / "py.csv").read_bytes() == want
+    stripped = [n.strip(".pdb") for n in names]
+    with native_csv.CsvWriter(str(tmp_path / "nat.csv")) as w:                  # (header decided by the first listing)
+        w.write_ssm(table, off, seqs, stripped, nb if cen else None, dataset="P53", pick_best=pick, include_cys=cys, n_threads=2, wt_cells=wts)
+    assert (tmp_path / "nat.csv").read_bytes() == want
+    # one rank's share of a sharded scan: protein 1 alone, no header, with its running index in the whole listing
+    per = 1 if pick else 20 if cys else 19
+    first1 = sum(c != "-" for c in seqs[0]) * per
+    with native_csv.CsvWriter(str(tmp_path / "part.csv"), header=False, pick_best=pick) as w:
+        nbytes = w.write_ssm(table[off[1]:], off[1:] - off[1], seqs[1:], stripped[1:], nb[off[1]:] if cen else None, dataset="P53",
+                             pick_best=pick, include_cys=cys, n_threads=2, wt_cells=wts[1:], first_rows=[first1], want_bytes=True)
+    part = (tmp_path / "part.csv").read_bytes()
+    assert want.endswith(part) and nbytes.tolist() == [len(part)] and native_csv.header_text(0, pick) == want[:want.index(b"\n") + 1]
+
+
+def test_custom_inference_csv_equals_the_file_made_by_pandas(tmp_path):
+    from thermompnn_amd import custom_inference, native_csv
+    g = np.load(os.path.join(GOLDEN, "csv", "csv_inputs.npz"))
+    want = open(os.path.join(GOLDEN, "csv", "custom_inference.csv"), "rb").read()
+    off, seq, tab = g["offsets"], str(g["seqs"][1]), g["table"][g["offsets"][1]:g["offsets"][2]]
+    rows = [{"Model": "ThermoMPNN", "Dataset": "2OCJ", "ddG_pred": float(tab[pos, a]), "position": pos, "wildtype": wt,
+             "mutation": AA20[a], "pdb": "2OCJ", "chain": "A"} for pos, wt in enumerate(seq) if wt != "-" for a in range(20)]
+    custom_inference.write_csv(rows, str(tmp_path / "py.csv"))
+    assert (tmp_path / "py.csv").read_bytes() == want
+    with native_csv.CsvWriter(str(tmp_path / "nat.csv"), native_csv.SCHEMA_CUSTOM_INFERENCE) as w:
+        w.write_ssm(tab, np.array([0, len(seq)], np.int32), [seq], ["2OCJ"], dataset="2OCJ", chain="A", include_cys=True)
+    assert (tmp_path / "nat.csv").read_bytes() == want
+
+
 def test_native_csv_listed_and_custom_inference_schema(tmp_path):
     from thermompnn_amd import custom_inference, native_csv, ssm_scan
     from thermompnn_amd._lib import TmpnnError

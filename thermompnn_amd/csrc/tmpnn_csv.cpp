@@ -110,8 +110,16 @@ struct tmpnn_csv {
     int schema = 0;
     int64_t rows = 0;          // data rows written so far = the next running index
     int64_t bytes = 0;         // file offset of the next byte
+    bool header = true;        // false: a part file of a sharded scan (no header line; tmpnn_csv_open_ex NO_HEADER)
+    bool pick_header = false;  // the header line ends in ",dupe_detector" (PICK_BEST listings, SSM.py:161)
     std::string path;
 };
+
+static const char *header_text(int schema, bool pick) {
+    if (schema == 1) return ",Model,Dataset,ddG_pred,position,wildtype,mutation,pdb,chain\n";
+    return pick ? ",WT Seq,Model,Dataset,ddG_pred,position,wildtype,mutation,neighbors,best_AA,pdb,dupe_detector\n"
+                : ",WT Seq,Model,Dataset,ddG_pred,position,wildtype,mutation,neighbors,best_AA,pdb\n";
+}
 
 static bool write_all_at(int fd, const char *p, size_t n, int64_t off) {
     while (n) {
@@ -122,23 +130,35 @@ static bool write_all_at(int fd, const char *p, size_t n, int64_t off) {
     return true;
 }
 
-extern "C" int tmpnn_csv_open(const char *path, int schema, tmpnn_csv_t **out) {
+extern "C" int tmpnn_csv_open_ex(const char *path, int schema, int flags, tmpnn_csv_t **out) {
     if (!path || !out || schema < 0 || schema > 1) return tm_set_error(TMPNN_E_INVALID, "csv_open: bad argument");
     const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
     if (fd < 0) return tm_set_error(TMPNN_E_INVALID, "csv_open: cannot create %s: %s", path, strerror(errno));
-    const char *hdr = schema == 0 ? ",WT Seq,Model,Dataset,ddG_pred,position,wildtype,mutation,neighbors,best_AA,pdb\n"
-                                  : ",Model,Dataset,ddG_pred,position,wildtype,mutation,pdb,chain\n";
+    const bool with_header = !(flags & TMPNN_CSV_NO_HEADER), pick = schema == 0 && (flags & TMPNN_CSV_PICK_BEST);
+    const char *hdr = header_text(schema, pick);
     const int rc = tm_host_guard("csv_open", [&]() -> int {
         std::unique_ptr<tmpnn_csv> c(new tmpnn_csv());
-        c->fd = fd; c->schema = schema; c->path = path;
-        if (!write_all_at(fd, hdr, strlen(hdr), 0))
-            return tm_set_error(TMPNN_E_INVALID, "csv_open: write to %s failed: %s", path, strerror(errno));
-        c->bytes = (int64_t)strlen(hdr);
+        c->fd = fd; c->schema = schema; c->path = path; c->header = with_header; c->pick_header = pick;
+        if (with_header) {
+            if (!write_all_at(fd, hdr, strlen(hdr), 0))
+                return tm_set_error(TMPNN_E_INVALID, "csv_open: write to %s failed: %s", path, strerror(errno));
+            c->bytes = (int64_t)strlen(hdr);
+        }
         *out = c.release();
         return TMPNN_OK;
     });
     if (rc != TMPNN_OK) close(fd);
     return rc;
+}
+extern "C" int tmpnn_csv_open(const char *path, int schema, tmpnn_csv_t **out) { return tmpnn_csv_open_ex(path, schema, 0, out); }
+
+extern "C" int tmpnn_csv_header(int schema, int flags, char *buf, int cap) {
+    if (schema < 0 || schema > 1 || !buf) return tm_set_error(TMPNN_E_INVALID, "csv_header: bad argument");
+    const char *h = header_text(schema, schema == 0 && (flags & TMPNN_CSV_PICK_BEST));
+    const int n = (int)strlen(h);
+    if (cap <= n) return tm_set_error(TMPNN_E_INVALID, "csv_header: buffer of %d bytes, need %d", cap, n + 1);
+    memcpy(buf, h, (size_t)n + 1);
+    return n;
 }
 
 extern "C" int tmpnn_csv_close(tmpnn_csv_t *c, int64_t *rows_out, int64_t *bytes_out) {
@@ -161,25 +181,45 @@ extern "C" int tmpnn_csv_close(tmpnn_csv_t *c, int64_t *rows_out, int64_t *bytes
 //   ddG (first minimum; C excluded unless TMPNN_CSV_INCLUDE_CYS); without PICK_BEST, rows mutating to C are dropped unless
 //   INCLUDE_CYS (SSM.py:153-166). Both schemas honour the flags; the custom_inference layout is written with INCLUDE_CYS
 //   (that script lists all 20 mutants).
-extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
-                                   const char *const *seqs, const char *const *wt_cells, const char *const *names, const int32_t *neighbors,
-                                   const char *model, const char *dataset, const char *const *datasets, const char *chain,
-                                   int flags, int n_threads) {
+//   first_rows (may be NULL) [n]: the running index of every protein's first row when it is not the writer's own count — a rank of
+//   a sharded scan formats ITS proteins with the indices they have in the one output file (dist.scan_files_to_csv);
+//   bytes_out (may be NULL) [n]: bytes of text written for each protein (what the ranks exchange to place their text).
+extern "C" int tmpnn_csv_write_ssm_ex(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
+                                      const char *const *seqs, const char *const *wt_cells, const char *const *names, const int32_t *neighbors,
+                                      const char *model, const char *dataset, const char *const *datasets, const char *chain,
+                                      int flags, int n_threads, const int64_t *first_rows, int64_t *bytes_out) {
     if (!c || !offsets || n < 0 || ld < 20 || (n > 0 && (!table || !seqs || !names)))
         return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: bad argument");
     return tm_host_guard("csv_write_ssm", [&]() -> int {
     const bool pick = flags & TMPNN_CSV_PICK_BEST, cys = flags & TMPNN_CSV_INCLUDE_CYS;
     const int schema = c->schema;
-    // running index of every protein's first row
-    std::vector<int64_t> first((size_t)n + 1);
+    const bool dupe = pick && schema == 0;                  // the reference's PICK_BEST frames carry one more column (SSM.py:161-162)
+    if (dupe != c->pick_header) {
+        // a file opened with tmpnn_csv_open (no flags) takes its header from the first listing written into it
+        if (c->rows != 0 || (c->header && c->bytes != (int64_t)strlen(header_text(schema, c->pick_header))))
+            return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: %s: PICK_BEST must be the same for every listing of a file", c->path.c_str());
+        if (c->header) {
+            const char *hdr = header_text(schema, dupe);
+            if (!write_all_at(c->fd, hdr, strlen(hdr), 0))
+                return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: write to %s failed: %s", c->path.c_str(), strerror(errno));
+            c->bytes = (int64_t)strlen(hdr);
+        }
+        c->pick_header = dupe;
+    }
+    // running index of every protein's first row, and its number of rows
+    std::vector<int64_t> first((size_t)n + 1), nrows_of((size_t)n);
     first[0] = c->rows;
+    int64_t total_rows = 0;
     for (int i = 0; i < n; ++i) {
         const int32_t L = offsets[i + 1] - offsets[i];
         if (L < 0 || !seqs[i] || (int64_t)strlen(seqs[i]) != L)
             return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: protein %d: sequence length does not match its %d table rows", i, L);
         int64_t npos = 0;
         for (int32_t k = 0; k < L; ++k) npos += seqs[i][k] != '-';
-        first[i + 1] = first[i] + npos * (pick ? 1 : (cys ? 20 : 19));
+        nrows_of[i] = npos * (pick ? 1 : (cys ? 20 : 19));
+        if (first_rows) first[i] = first_rows[i];
+        first[i + 1] = first[i] + nrows_of[i];
+        total_rows += nrows_of[i];
     }
     const std::string f_model = csv_field(model), f_chain = csv_field(chain);
     std::atomic<int> next(0), write_errno(0);
@@ -199,13 +239,16 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
             const float *tab = table + (size_t)offsets[i] * ld;
             const int32_t *nb = neighbors ? neighbors + offsets[i] : nullptr;
             const std::string f_name = csv_field(names[i]);
+            // the dupe_detector cell: the name with the position appended, quoted as a whole when the name needs quoting
+            const bool f_dupe_quoted = f_name.size() >= 2 && f_name[0] == '"' && f_name != names[i];
+            const std::string f_dupe = f_dupe_quoted ? f_name.substr(1, f_name.size() - 2) : f_name;
             const std::string f_data = csv_field(datasets ? datasets[i] : dataset);
             // the cells between the running index and the ddG value, and after the per-row cells
             std::string head = ",";
             if (schema == 0) { head += csv_field(wt_cells && wt_cells[i] ? wt_cells[i] : seq); head += ","; }
             head += f_model; head += ","; head += f_data; head += ",";
-            const int64_t nrows = first[i + 1] - first[i];
-            const size_t per_row = 20 + head.size() + 26 + 12 + 4 + 12 + 2 + f_name.size() + f_chain.size() + 4;
+            const int64_t nrows = nrows_of[i];
+            const size_t per_row = 20 + head.size() + 26 + 12 + 4 + 12 + 2 + 2 * f_name.size() + 12 + f_chain.size() + 4;
             // rows of positions [p0, p1) -> buf (from its start); returns the running index after them
             auto format = [&](int32_t p0, int32_t p1, int64_t row, size_t *len_out) {
                 char *o = buf.data();
@@ -218,16 +261,16 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
                         int bi = -1;
                         double bv = 0;
                         for (int a = 0; a < 20; ++a) {
-                            if (!cys && kAA20[a] == 'C') continue;
+                            if ((!cys && kAA20[a] == 'C') || t[a] != t[a]) continue;       // (idxmin skips missing values)
                             if (bi < 0 || (double)t[a] < bv) { bi = a; bv = t[a]; }
                         }
-                        best = kAA20[bi];
+                        best = bi < 0 ? 0 : kAA20[bi];
                     }
                     for (int a = 0; a < (pick ? 1 : 20); ++a) {
                         if (!pick && !cys && kAA20[a] == 'C') continue;
                         o = put_int(o, row++);
                         memcpy(o, head.data(), head.size()); o += head.size();
-                        o += repr_double((double)t[a], o);
+                        if (t[a] == t[a]) o += repr_double((double)t[a], o);      // (a missing value is an empty cell in pandas' CSV)
                         *o++ = ',';
                         o = put_int(o, pos);
                         *o++ = ','; *o++ = wt; *o++ = ','; *o++ = kAA20[a]; *o++ = ',';
@@ -237,6 +280,13 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
                             if (best) *o++ = best;
                             *o++ = ',';
                             memcpy(o, f_name.data(), f_name.size()); o += f_name.size();
+                            if (dupe) {                                   // 'dupe_detector' = pdb + str(position) (SSM.py:161)
+                                *o++ = ',';
+                                if (f_dupe_quoted) *o++ = '"';
+                                memcpy(o, f_dupe.data(), f_dupe.size()); o += f_dupe.size();
+                                o = put_int(o, pos);
+                                if (f_dupe_quoted) *o++ = '"';
+                            }
                         } else {
                             memcpy(o, f_name.data(), f_name.size()); o += f_name.size();
                             *o++ = ',';
@@ -267,6 +317,7 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
                     ticket_taken = ticket_returned = true;
                 }
                 cv.notify_all();
+                if (bytes_out) bytes_out[i] = (int64_t)len;
                 if (len && !write_all_at(c->fd, buf.data(), len, at)) write_failed();
             } else {
                 const int32_t step = (int32_t)std::max<size_t>(1, kBlock / (rows_per_pos * per_row));
@@ -277,12 +328,14 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
                     ticket_taken = true;
                 }
                 int64_t row = first[i], at = off;                  // (this thread owns the tail of the file until it bumps `commit`)
+                const int64_t at0 = at;
                 for (int32_t p0 = 0; p0 < L; p0 += step) {
                     size_t len = 0;
                     row = format(p0, std::min<int32_t>(L, p0 + step), row, &len);
                     if (len && !write_all_at(c->fd, buf.data(), len, at)) write_failed();
                     at += (int64_t)len;
                 }
+                if (bytes_out) bytes_out[i] = at - at0;
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     off = at;
@@ -305,10 +358,17 @@ extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, c
     };
     tm_run_pool(std::max(1, std::min(n_threads, std::max(n, 1))), work);
     if (failed) return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: write to %s failed: %s", c->path.c_str(), strerror(write_errno.load()));
-    c->rows = first[n];
+    c->rows += total_rows;
     c->bytes = off;
     return TMPNN_OK;
     });
+}
+extern "C" int tmpnn_csv_write_ssm(tmpnn_csv_t *c, const float *table, int ld, const int32_t *offsets, int n,
+                                   const char *const *seqs, const char *const *wt_cells, const char *const *names, const int32_t *neighbors,
+                                   const char *model, const char *dataset, const char *const *datasets, const char *chain,
+                                   int flags, int n_threads) {
+    return tmpnn_csv_write_ssm_ex(c, table, ld, offsets, n, seqs, wt_cells, names, neighbors, model, dataset, datasets, chain, flags, n_threads,
+                                  nullptr, nullptr);
 }
 
 // An explicit mutation list (BASELINE config 4; ssm_scan --mutations): triples [m, 3] int64 HOST of (protein, 0-based

@@ -219,7 +219,7 @@ def agree_or_raise(err: Optional[str], group=None) -> None:
 
 
 def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, group=None, centrality: bool = False,
-               k_neighbors: Optional[int] = None, **pipeline_kw):
+               k_neighbors: Optional[int] = None, device_tables: Optional[bool] = None, **pipeline_kw):
     """PDB files -> ddG tables on rank 0, sharded over the group's GPUs, each rank running the parse || forward || copy-back
     pipeline (thermompnn_amd.pipeline.scan_files) on its LPT shard and ONE gather to rank 0 at the end.
 
@@ -238,26 +238,25 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
         shard = list(range(n))
         info = None
     else:
-        mine, err, part = list(range(rank, n, world)), None, {}
-        try:
-            part = {i: (len(p["S"]), p["seq"], p["name"]) for i, p in
-                    zip(mine, native_pdb.parse_pdbs([paths[i] for i in mine], [chains[i] for i in mine]))}
-        except Exception as e:           # noqa: BLE001
-            err = f"rank {rank}: {e}"
-        parts = [None] * world
-        dist.all_gather_object(parts, (err, part), group=group)
-        raise_first_error([p[0] for p in parts])
-        info = {k: v for p in parts for k, v in p[1].items()}
+        info = _length_prepass(paths, chains, rank, world, group)
         shard = partition_proteins([info[i][0] for i in range(n)], world, K)[rank]
+    # over RCCL the shard's tables never leave the device between the forwards and the gather (round 5; rounds 3-4 copied every
+    # chunk back, concatenated on the host and uploaded the result again for the collective)
+    # (``device_tables``: None = when the group's backend is nccl; True forces it — the one-device gloo test mode exercises the path)
+    on_device = world > 1 and (dist.get_backend(group) == "nccl" if device_tables is None else bool(device_tables))
+    dev_table = torch.empty((sum(info[i][0] for i in shard), 21), dtype=torch.float32, device=engine.device) if on_device else None
     C_ = 22 if centrality else 21
     acc, seqs_l, names_l, lens_l = [], [], [], []
 
     def sink(ch):
-        t = np.empty((ch.T, C_), np.float32)
-        t[:, :21] = ch.table
-        if centrality:
-            t[:, 21] = ch.neighbors
-        acc.append(t)
+        if dev_table is None:
+            t = np.empty((ch.T, C_), np.float32)
+            t[:, :21] = ch.table
+            if centrality:
+                t[:, 21] = ch.neighbors
+            acc.append(t)
+        elif centrality:
+            acc.append(ch.neighbors.astype(np.float32))
         seqs_l.extend(ch.seqs())
         names_l.extend(ch.names)
         lens_l.extend(int(x) for x in np.diff(ch.offsets))
@@ -265,11 +264,12 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
     err, stats = None, None
     try:
         stats = pipeline.scan_files(engine, [paths[i] for i in shard], [chains[i] for i in shard], sink, centrality=centrality,
-                                    **pipeline_kw)
+                                    device_table=dev_table, **pipeline_kw)
     except Exception as e:               # noqa: BLE001
         err = f"rank {rank}: {type(e).__name__}: {e}"
     agree_or_raise(err, group)
-    local = np.concatenate(acc) if acc else np.zeros((0, C_), np.float32)
+    if dev_table is None:
+        local = np.concatenate(acc) if acc else np.zeros((0, C_), np.float32)
     if world == 1:
         lengths, seqs, names, table = lens_l, seqs_l, names_l, local
     else:
@@ -278,10 +278,13 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
         assert lens_l == [lengths[i] for i in shard], "a file changed between the length pre-pass and the scan"
         shards = partition_proteins(lengths, world, K)
         rows = [sum(lengths[i] for i in s) for s in shards]
-        backend = dist.get_backend(group)
-        loc_t = torch.from_numpy(local)
-        if backend == "nccl":
-            loc_t = loc_t.to(engine.device)
+        if dev_table is not None:
+            loc_t = dev_table
+            if centrality:                                   # the neighbour counts ride along as the 22nd column: one collective
+                cen = torch.from_numpy(np.concatenate(acc) if acc else np.zeros(0, np.float32)).to(engine.device)
+                loc_t = torch.cat([dev_table, cen[:, None]], dim=1)
+        else:
+            loc_t = torch.from_numpy(local)
         got = gather_tables_root(loc_t, rows, group, 0)
         table = None
         if got is not None:                                  # rank 0: per-rank shard tables -> the original file order
@@ -299,6 +302,153 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
         out["table"] = np.ascontiguousarray(table[:, :21])
         out["neighbors"] = np.rint(table[:, 21]).astype(np.int32) if centrality else None
     return out
+
+
+def _length_prepass(paths, chains, rank: int, world: int, group=None) -> dict:
+    """Rank r parses files r, r + N, ... and the (length, sequence, name) triples are exchanged: -> {file index: triple} on every
+    rank. A file that fails on ONE rank fails EVERY rank through the same collective."""
+    from . import native_pdb
+    mine, err, part = list(range(rank, len(paths), world)), None, {}
+    try:
+        part = {i: (len(p["S"]), p["seq"], p["name"]) for i, p in
+                zip(mine, native_pdb.parse_pdbs([paths[i] for i in mine], [chains[i] for i in mine]))}
+    except Exception as e:           # noqa: BLE001
+        err = f"rank {rank}: {e}"
+    parts = [None] * world
+    dist.all_gather_object(parts, (err, part), group=group)
+    raise_first_error([p[0] for p in parts])
+    return {k: v for p in parts for k, v in p[1].items()}
+
+
+def _copy_range(src_fd: int, dst_fd: int, src_off: int, dst_off: int, n: int) -> None:
+    """n bytes of src at src_off -> dst at dst_off, inside the kernel where the platform offers it (copy_file_range), else
+    through a buffer."""
+    import os
+    use_cfr = hasattr(os, "copy_file_range")
+    while n > 0:
+        if use_cfr:
+            try:
+                k = os.copy_file_range(src_fd, dst_fd, min(n, 1 << 30), src_off, dst_off)
+                if k > 0:
+                    src_off, dst_off, n = src_off + k, dst_off + k, n - k
+                    continue
+            except OSError:
+                pass
+            use_cfr = False
+        buf = os.pread(src_fd, min(n, 8 << 20), src_off)
+        if not buf:
+            raise OSError("part file shorter than its recorded length")
+        os.pwrite(dst_fd, buf, dst_off)
+        src_off, dst_off, n = src_off + len(buf), dst_off + len(buf), n - len(buf)
+
+
+def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], out: str, model_name: str = "ThermoMPNN",
+                      dataset: str = "custom", pick_best: bool = False, include_cys: bool = False, centrality: bool = False,
+                      group=None, k_neighbors: Optional[int] = None, n_threads: int = 0, run_pipeline=None, **pipeline_kw):
+    """PDB files -> ONE CSV in the reference's layout (analysis/SSM.py:102-176), every rank FORMATTING its own shard (round 5; until
+    round 4 every table went to rank 0, which formatted the whole listing alone: one writer does 7-17 M predictions/s against
+    > 100 M/s per GPU, so an 8-GPU scan to CSV ran at the one-GPU rate).
+
+      1. length pre-pass + LPT shards as in ``scan_files``; every rank knows every sequence, hence every protein's number of rows
+         and the running index of its first row in the final listing;
+      2. each rank runs the parse || forward || write pipeline on its shard; the writer thread formats chunk after chunk with the
+         FINAL running indices into a rank-local part file beside ``out`` and records the bytes of text of every protein;
+      3. ONE ``all_gather_object`` of those byte counts -> every protein's byte offset in the final file; rank 0 creates ``out``
+         (header, ftruncate to the total), every rank copies its proteins from its part file to their offsets
+         (copy_file_range), part files are removed.
+    The result is byte-identical to the one-rank file (tests: world-2 gloo with a stand-in pipeline on CPU, two ranks on one GPU
+    with the real engine). ``run_pipeline``: the function used as ``pipeline.scan_files`` (tests inject a CPU stand-in).
+    -> (rows, stats) on every rank (rows = of the whole file)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from . import native_csv, pipeline
+    run_pipeline = run_pipeline or pipeline.scan_files
+    n = len(paths)
+    chains = list(chains) if chains is not None else [None] * n
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    K = int(k_neighbors or engine.K)
+    nt = n_threads or max(1, pipeline.usable_cpus() - 1)
+    if world == 1:
+        from . import ssm_scan
+        return ssm_scan.scan_to_file(engine, paths, chains, out, model_name, dataset, pick_best, include_cys, centrality,
+                                     n_threads=nt, **pipeline_kw)
+    info = _length_prepass(paths, chains, rank, world, group)
+    lengths = [info[i][0] for i in range(n)]
+    shard = partition_proteins(lengths, world, K)[rank]
+    per = 1 if pick_best else (20 if include_cys else 19)
+    rows_of = [sum(c != "-" for c in info[i][1]) * per for i in range(n)]
+    first_row = np.concatenate([[0], np.cumsum(rows_of)]).astype(np.int64)
+    part = f"{out}.part{rank}"
+    nbytes = {}
+    err, stats = None, None
+    w = None
+    try:
+        w = native_csv.CsvWriter(part, native_csv.SCHEMA_SSM, header=False, pick_best=pick_best)
+        done = [0]
+
+        def sink(ch):
+            ids = shard[done[0]:done[0] + ch.n]
+            got = w.write_ssm(ch.table, ch.offsets, ch.seq_ptrs, [x.strip(".pdb") for x in ch.names], neighbors=ch.neighbors,
+                              model=model_name, dataset=dataset, pick_best=pick_best, include_cys=include_cys, n_threads=nt,
+                              first_rows=[int(first_row[i]) for i in ids], want_bytes=True)
+            for i, b in zip(ids, got):
+                nbytes[i] = int(b)
+            done[0] += ch.n
+
+        stats = run_pipeline(engine, [paths[i] for i in shard], [chains[i] for i in shard], sink, centrality=centrality, **pipeline_kw)
+        if done[0] != len(shard):
+            raise RuntimeError(f"the pipeline delivered {done[0]} of this rank's {len(shard)} proteins")
+    except Exception as e:               # noqa: BLE001
+        err = f"rank {rank}: {type(e).__name__}: {e}"
+    finally:
+        if w is not None:
+            w.close()
+    try:
+        agree_or_raise(err, group)
+        parts = [None] * world
+        dist.all_gather_object(parts, nbytes, group=group)
+        allb = {k: v for p in parts for k, v in p.items()}
+        hdr = native_csv.header_text(native_csv.SCHEMA_SSM, pick_best)
+        offs = np.concatenate([[len(hdr)], len(hdr) + np.cumsum([allb[i] for i in range(n)])]).astype(np.int64)
+        err = None
+        if rank == 0:
+            try:
+                fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                try:
+                    os.pwrite(fd, hdr, 0)
+                    os.ftruncate(fd, int(offs[-1]))
+                finally:
+                    os.close(fd)
+            except OSError as e:
+                err = f"rank 0: cannot create {out}: {e}"
+        agree_or_raise(err, group)                           # (also the barrier behind which the file exists)
+        err = None
+        try:
+            src, dst = os.open(part, os.O_RDONLY), os.open(out, os.O_WRONLY)
+            try:
+                jobs, pos = [], 0
+                for i in shard:                              # consecutive proteins of the final file are copied as one range
+                    if jobs and jobs[-1][1] + jobs[-1][2] == int(offs[i]) and jobs[-1][0] + jobs[-1][2] == pos:
+                        jobs[-1][2] += allb[i]
+                    else:
+                        jobs.append([pos, int(offs[i]), allb[i]])
+                    pos += allb[i]
+                with ThreadPoolExecutor(max_workers=max(1, min(nt, 8))) as ex:
+                    list(ex.map(lambda j: _copy_range(src, dst, j[0], j[1], j[2]), jobs))
+            finally:
+                os.close(src)
+                os.close(dst)
+        except OSError as e:
+            err = f"rank {rank}: {e}"
+        agree_or_raise(err, group)
+    finally:
+        try:
+            os.remove(part)
+        except OSError:
+            pass
+    return int(first_row[-1]), stats
 
 
 def select_mutations(tables: Sequence[torch.Tensor], triples) -> torch.Tensor:

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 
 SCHEMA_SSM, SCHEMA_CUSTOM_INFERENCE = 0, 1
-PICK_BEST, INCLUDE_CYS = 1, 2
+PICK_BEST, INCLUDE_CYS, NO_HEADER = 1, 2, 4
 
 
 def _cstrs(items: Sequence) -> C.Array:
@@ -30,6 +30,14 @@ def _cstrs(items: Sequence) -> C.Array:
     return arr
 
 
+def header_text(schema: int = SCHEMA_SSM, pick_best: bool = False) -> bytes:
+    buf = C.create_string_buffer(256)
+    n = _lib.load().tmpnn_csv_header(int(schema), PICK_BEST if pick_best else 0, buf, 256)
+    if n < 0:
+        _lib.check(n, "tmpnn_csv_header")
+    return buf.raw[:n]
+
+
 def format_double(v: float) -> str:
     buf = C.create_string_buffer(40)
     _lib.load().tmpnn_csv_format_double(float(v), buf)
@@ -39,18 +47,24 @@ def format_double(v: float) -> str:
 class CsvWriter:
     """One output file; ``write_ssm`` / ``write_listed`` append chunks (the running index continues)."""
 
-    def __init__(self, path: str, schema: int = SCHEMA_SSM):
+    def __init__(self, path: str, schema: int = SCHEMA_SSM, header: bool = True, pick_best: bool = False):
+        """``header=False``: a part file of a sharded scan (no header line); ``pick_best``: the header carries the reference's
+        extra ``dupe_detector`` column at once (otherwise the first ``write_ssm`` decides)."""
         self.lib = _lib.load()
         self.h = C.c_void_p()
-        _lib.check(self.lib.tmpnn_csv_open(os.fsencode(path), int(schema), C.byref(self.h)), "tmpnn_csv_open")
+        flags = (0 if header else NO_HEADER) | (PICK_BEST if pick_best else 0)
+        _lib.check(self.lib.tmpnn_csv_open_ex(os.fsencode(path), int(schema), flags, C.byref(self.h)), "tmpnn_csv_open")
         self.path, self.rows, self.bytes = path, 0, 0
 
     def write_ssm(self, table: np.ndarray, offsets: np.ndarray, seqs: Sequence, names: Sequence,
                   neighbors: Optional[np.ndarray] = None, model: str = "ThermoMPNN", dataset: str = "custom",
                   datasets: Optional[Sequence] = None, chain: str = "", pick_best: bool = False, include_cys: bool = False,
-                  n_threads: int = 0, wt_cells: Optional[Sequence] = None) -> None:
+                  n_threads: int = 0, wt_cells: Optional[Sequence] = None, first_rows: Optional[Sequence[int]] = None,
+                  want_bytes: bool = False) -> Optional[np.ndarray]:
         """table: host float32 [T, ld >= 20] (C-contiguous); offsets int32 [n+1]; seqs / names: str, bytes or char* addresses;
-        wt_cells: per-protein 'WT Seq' cells when they are not the parsed sequences (a dataset's own wild-type strings)."""
+        wt_cells: per-protein 'WT Seq' cells when they are not the parsed sequences (a dataset's own wild-type strings);
+        first_rows: the running index of each protein's first row when this writer holds one rank's share of a larger listing;
+        want_bytes: -> int64 [n] bytes of text written per protein."""
         table = np.ascontiguousarray(table, dtype=np.float32)
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
         n = offsets.size - 1
@@ -61,10 +75,15 @@ class CsvWriter:
         cw = _cstrs(wt_cells) if wt_cells is not None else None
         assert wt_cells is None or len(wt_cells) == n
         flags = (PICK_BEST if pick_best else 0) | (INCLUDE_CYS if include_cys else 0)
-        _lib.check(self.lib.tmpnn_csv_write_ssm(self.h, table.ctypes.data, table.shape[1], offsets.ctypes.data, n, cs, cw, cn,
-                                                None if nb is None else nb.ctypes.data, model.encode(), dataset.encode(), cd,
-                                                chain.encode(), flags, n_threads or min(16, os.cpu_count() or 1)),
+        fr = None if first_rows is None else np.ascontiguousarray(first_rows, dtype=np.int64)
+        assert fr is None or fr.size == n
+        nbytes = np.zeros(n, np.int64) if want_bytes else None
+        _lib.check(self.lib.tmpnn_csv_write_ssm_ex(self.h, table.ctypes.data, table.shape[1], offsets.ctypes.data, n, cs, cw, cn,
+                                                   None if nb is None else nb.ctypes.data, model.encode(), dataset.encode(), cd,
+                                                   chain.encode(), flags, n_threads or min(16, os.cpu_count() or 1),
+                                                   None if fr is None else fr.ctypes.data, None if nbytes is None else nbytes.ctypes.data),
                    "tmpnn_csv_write_ssm")
+        return nbytes
 
     def write_listed(self, table: np.ndarray, offsets: np.ndarray, seqs: Sequence, names: Sequence, triples: np.ndarray,
                      neighbors: Optional[np.ndarray] = None, model: str = "ThermoMPNN", dataset: str = "custom") -> None:

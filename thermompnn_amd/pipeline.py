@@ -98,11 +98,13 @@ class Chunk:
     n: int                           # proteins
     T: int                           # residues
     offsets: np.ndarray              # int32 [n+1]
-    table: np.ndarray                # float32 [T, 21] view of the pinned slot: ddG of mutating to ALPHABET[a]
+    table: Optional[np.ndarray]      # float32 [T, 21] view of the pinned slot: ddG of mutating to ALPHABET[a] (None when the scan
+                                     # keeps the tables on the device: ``device_table``)
     neighbors: Optional[np.ndarray]  # int32 [T] (#CA within the radius) when the scan computes centrality
     seq_ptrs: List[int]              # char* of every parsed sequence (tmpnn_pdb_seq), for the native writer
     names: List[str]
     handles: C.Array = field(repr=False, default=None)
+    row0: int = 0                    # first row of this chunk in the scan's packed residue axis (= its rows of ``device_table``)
 
     def seqs(self) -> List[str]:
         return [C.string_at(p).decode() for p in self.seq_ptrs]
@@ -123,9 +125,12 @@ class ScanStats:
 
 def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, sink: Callable[[Chunk], None] = None,
                centrality: bool = False, radius: float = 10.0, chunk_files: int = 96, chunk_residues: int = 1 << 18,
-               parse_threads: int = 0, depth: int = 3) -> ScanStats:
+               parse_threads: int = 0, depth: int = 3, device_table: Optional[torch.Tensor] = None) -> ScanStats:
     """Run the scan; ``sink(chunk)`` is called in file order from the writer thread. ``chunk_files`` files are parsed per
-    chunk (fewer when their residues would exceed ``chunk_residues``: the chunk is split before the forward)."""
+    chunk (fewer when their residues would exceed ``chunk_residues``: the chunk is split before the forward).
+    ``device_table`` (float32 [>= total residues, 21] on the engine's device): the tables stay THERE — chunk k's forward writes its
+    rows ``[row0, row0 + T)`` of it and nothing is copied back (``chunk.table`` is None): what a multi-rank scan gathers over
+    RCCL without a host round trip (dist.scan_files)."""
     lib = _lib.load()
     n_files = len(paths)
     chains = list(chains) if chains is not None else [None] * n_files
@@ -136,6 +141,8 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
     from .native_pdb import _chains_arg
     parse_threads = parse_threads or max(1, usable_cpus() - 2)
     dev = engine.device
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)            # the CALLER's stream: every enqueue of this scan, the writer thread's rerun too
     # pinned staging slots are kept on the engine between scans (pinning a few MB costs milliseconds: hipHostMalloc)
     pool: List[_Staging] = getattr(engine, "_staging_pool", None) or []
     engine._staging_pool = []                              # (taken: a concurrent scan on the same engine gets fresh ones)
@@ -195,7 +202,7 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
                 item = q_done.get()
                 if item is None:
                     return
-                index, first, slot, sub, n, T, max_len, lay, ev, dev_in = item
+                index, first, slot, sub, n, T, max_len, lay, ev, row0 = item
                 try:
                     if not stop.is_set():
                         t0 = time.perf_counter()
@@ -206,11 +213,12 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
                         if st & _lib.STATUS_MAXLEN:
                             check(lib.tmpnn_status_error(_lib.STATUS_MAXLEN), "tmpnn_ssm_forward")
                         if st & _lib.STATUS_RANGE:
-                            _rerun(slot, n, T, max_len, lay)
+                            _rerun(slot, n, T, max_len, lay, row0)
                         t0 = time.perf_counter()
                         off = np.frombuffer((C.c_int32 * (n + 1)).from_address(slot.inp.data_ptr() + lay["offsets"]), dtype=np.int32)
                         if sink is not None:
-                            sink(Chunk(index=index, first=first, n=n, T=T, offsets=off, table=slot.out.numpy()[:T],
+                            sink(Chunk(index=index, first=first, n=n, T=T, offsets=off, row0=row0,
+                                       table=slot.out.numpy()[:T] if device_table is None else None,
                                        neighbors=slot.cen.numpy()[:T] if centrality else None,
                                        seq_ptrs=[lib.tmpnn_pdb_seq(C.c_void_p(sub[i])) for i in range(n)],
                                        names=item_names[index], handles=sub))
@@ -231,7 +239,9 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
                     lib.tmpnn_pdb_free(C.c_void_p(item[3][i]))
                 free_slots.put(item[2])
 
-    def _rerun(slot, n, T, max_len, lay):
+    rerun_priv: dict = {}                      # the rerun's own workspace + status word (the engine's shared ones may be in use elsewhere)
+
+    def _rerun(slot, n, T, max_len, lay, row0):
         retry = engine.retry_precision
         if engine.precision != "f16x2" or not retry or retry == engine.precision:
             check(lib.tmpnn_status_error(_lib.STATUS_RANGE), f"tmpnn_ssm_forward[{engine.precision}]")
@@ -240,12 +250,19 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
         stats.reruns += 1
         host = slot.inp
         view = lambda name, dt, cnt: host[lay[name]:lay[name] + cnt * 4].view(dt)
-        with enqueue_lock, torch.cuda.device(dev):
+        # torch's current stream is thread-local: without this the retry would run on the device's DEFAULT stream, unordered with the
+        # caller's; it also gets a private workspace, like the scan's own forwards
+        with enqueue_lock, torch.cuda.device(dev), torch.cuda.stream(stream):
+            if "status" not in rerun_priv:
+                rerun_priv["status"] = torch.zeros(1, dtype=torch.int32, device=dev)
             res = engine.ssm_forward(view("X", torch.float32, T * 12).view(T, 4, 3), view("S", torch.int32, T),
                                      view("mask", torch.float32, T), view("ridx", torch.int32, T), view("cenc", torch.int32, T),
-                                     view("offsets", torch.int32, n + 1), max_len=max_len, precision=retry)
-            slot.out[:T].copy_(res["ddg"])
-            torch.cuda.current_stream(dev).synchronize()
+                                     view("offsets", torch.int32, n + 1), max_len=max_len, precision=retry, _private=rerun_priv)
+            if device_table is None:
+                slot.out[:T].copy_(res["ddg"])
+            else:
+                device_table[row0:row0 + T].copy_(res["ddg"])
+            stream.synchronize()
 
     item_names: dict = {}
     tp = threading.Thread(target=parser, name="tmpnn-parse", daemon=True)
@@ -257,34 +274,45 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
     dev_out: Optional[torch.Tensor] = None       # [cap, 21] ddG
     dev_cen: Optional[torch.Tensor] = None       # [cap] neighbour counts
     priv = {"status": torch.zeros(1, dtype=torch.int32, device=dev)}      # this scan's workspace + status word
+    cur_item = None                              # the chunk the GPU stage holds (its handles and slot go back if the stage fails)
+    row = 0
     try:
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev)
+        with torch.cuda.device(dev), torch.cuda.stream(stream):
             while True:
-                item = q_parsed.get()
+                item = cur_item = q_parsed.get()
                 if item is None:
                     break
                 index, first, slot, sub, n, T, max_len, lay, nbytes, names = item
                 item_names[index] = names
+                row0, row = row, row + T
                 if stop.is_set() or T == 0:
-                    q_done.put((index, first, slot, sub, n, T, max_len, lay, None, None))
+                    q_done.put((index, first, slot, sub, n, T, max_len, lay, None, row0))
+                    cur_item = None
                     continue
                 t0 = time.perf_counter()
                 ev = torch.cuda.Event()
                 with enqueue_lock:
                     if dev_in is None or dev_in.numel() < nbytes:
                         dev_in = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
-                    if dev_out is None or dev_out.shape[0] < T:
-                        dev_out = torch.empty((int(T * 1.25) + 64, 21), dtype=torch.float32, device=dev)
-                        dev_cen = torch.empty(dev_out.shape[0], dtype=torch.int32, device=dev)
+                    if device_table is not None:
+                        if row > device_table.shape[0]:
+                            raise ValueError(f"device_table holds {device_table.shape[0]} rows, the scan needs at least {row}")
+                        out_rows = device_table[row0:row]
+                    else:
+                        if dev_out is None or dev_out.shape[0] < T:
+                            dev_out = torch.empty((int(T * 1.25) + 64, 21), dtype=torch.float32, device=dev)
+                        out_rows = dev_out[:T]
+                    if centrality and (dev_cen is None or dev_cen.shape[0] < T):
+                        dev_cen = torch.empty(int(T * 1.25) + 64, dtype=torch.int32, device=dev)
                     dev_in[:nbytes].copy_(slot.inp[:nbytes], non_blocking=True)
                     sec = lambda name, dt, cnt: dev_in[lay[name]:lay[name] + cnt * 4].view(dt)
                     X = sec("X", torch.float32, T * 12).view(T, 4, 3)
                     offs = sec("offsets", torch.int32, n + 1)
                     engine.ssm_forward(X, sec("S", torch.int32, T), sec("mask", torch.float32, T), sec("ridx", torch.int32, T),
                                        sec("cenc", torch.int32, T), offs, max_len=max_len, check_status=False, _private=priv,
-                                       out={"ddg": dev_out[:T]})
-                    slot.out[:T].copy_(dev_out[:T], non_blocking=True)
+                                       out={"ddg": out_rows})
+                    if device_table is None:
+                        slot.out[:T].copy_(out_rows, non_blocking=True)
                     if centrality:
                         engine.centrality(X, sec("ca", torch.float32, T), offs, radius, out=dev_cen[:T])
                         slot.cen[:T].copy_(dev_cen[:T], non_blocking=True)
@@ -293,10 +321,16 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
                 stats.gpu_enqueue_s += time.perf_counter() - t0
                 stats.residues += T
                 stats.chunks += 1
-                q_done.put((index, first, slot, sub, n, T, max_len, lay, ev, dev_in))
+                q_done.put((index, first, slot, sub, n, T, max_len, lay, ev, row0))
+                cur_item = None
     except BaseException as e:                   # noqa: BLE001
         errors.append(e)
         stop.set()
+        if cur_item is not None:                 # the chunk this stage was holding when it failed: handles freed, slot returned
+            for i in range(cur_item[4]):
+                lib.tmpnn_pdb_free(C.c_void_p(cur_item[3][i]))
+            item_names.pop(cur_item[0], None)
+            free_slots.put(cur_item[2])
         while True:                              # unblock the parser
             try:
                 it = q_parsed.get(timeout=0.05)
@@ -313,6 +347,11 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
         q_done.put(None)
         tw.join()
         tp.join()
+        if errors:                               # a failed chunk's async H2D copy may still be reading its pinned slot: the next scan's
+            try:                                 # parser must not overwrite it under the copy
+                stream.synchronize()
+            except Exception:                    # noqa: BLE001 - the original error is the one to report
+                pass
         engine._staging_pool = slots                       # every slot is back in free_slots by now (both threads have ended)
     stats.wall_s = time.perf_counter() - t_wall
     if errors:

@@ -28,12 +28,15 @@ from .datasets import ALPHABET
 
 AA20 = ALPHABET[:-1]
 COLUMNS = ["WT Seq", "Model", "Dataset", "ddG_pred", "position", "wildtype", "mutation", "neighbors", "best_AA", "pdb"]
+# --pick_best frames carry one more column that the reference adds for drop_duplicates and never drops (SSM.py:161-162)
+COLUMNS_PICK_BEST = COLUMNS + ["dupe_detector"]
 
 
 def retrieve_best_mutants(ddg_table: np.ndarray, allow_cys: bool = True) -> List[str]:
     """Best (lowest ddG) mutant letter at each position of a [L, 20] table; first minimum wins like
     ``idxmin`` (SSM.py:32-42). Cysteine is excluded unless ``allow_cys``."""
     t = np.array(ddg_table[:, :20], dtype=np.float64, copy=True)
+    t[np.isnan(t)] = np.inf                                  # idxmin skips missing values
     if not allow_cys:
         t[:, AA20.index("C")] = np.inf
     return [AA20[i] for i in np.argmin(t, axis=1)]
@@ -94,19 +97,26 @@ def rows_for_protein(p: dict, table: np.ndarray, neighbors, model_name: str, dat
                 break                                            # one row per position (drop_duplicates keep='first')
             if not pick_best and not include_cys and mut == "C":
                 continue
-            rows.append({"WT Seq": seq, "Model": model_name, "Dataset": dataset, "ddG_pred": float(table[pos, a]),
+            v = float(table[pos, a])
+            rows.append({"WT Seq": p.get("wt", seq), "Model": model_name, "Dataset": dataset, "ddG_pred": "" if v != v else v,   # (NaN = a missing cell)
                          "position": pos, "wildtype": wt, "mutation": mut,
                          "neighbors": int(neighbors[pos]) if neighbors is not None else "",
                          "best_AA": best[pos] if best is not None else "", "pdb": name})
+            if pick_best:
+                rows[-1]["dupe_detector"] = name + str(pos)
     return rows
 
 
-def write_csv(rows, path: str) -> None:
+def write_csv(rows, path: str, pick_best: Optional[bool] = None) -> None:
+    """``pick_best`` (default: whether the rows carry the column) selects the header with ``dupe_detector``."""
+    if pick_best is None:
+        pick_best = bool(rows) and "dupe_detector" in rows[0]
+    cols = COLUMNS_PICK_BEST if pick_best else COLUMNS
     with open(path, "w", newline="") as fh:
         w = csv.writer(fh, lineterminator="\n")           # pandas' to_csv line ends (examples/ThermoMPNN_inference_2OCJ.csv)
-        w.writerow([""] + COLUMNS)
+        w.writerow([""] + cols)
         for i, r in enumerate(rows):
-            w.writerow([i] + [r[c] for c in COLUMNS])
+            w.writerow([i] + [r[c] for c in cols])
 
 
 def write_scan_csv(path: str, res: dict, model_name: str, dataset: str, pick_best: bool, include_cys: bool,
@@ -243,6 +253,9 @@ def main(argv=None):
     ap.add_argument("--mutations", default="", help="CSV (pdb,position,mutation): write only these mutants")
     ap.add_argument("--precision", default=None, choices=["f16x2", "bf16x3", "fp32"])
     ap.add_argument("--chunk_files", type=int, default=96, help="files per pipeline chunk (parse || forward || write overlap)")
+    ap.add_argument("--device_tables", action="store_true", default=False,
+                    help="multi-rank binary / listed output: keep every rank's tables on its GPU until the gather (automatic over "
+                         "RCCL; this forces it for other backends)")
     ap.add_argument("--allow_pickle", action="store_true", default=False,
                     help="read --model_path with the unrestricted pickle loader (it can execute code from the file); the default "
                          "restricted loader already reads Lightning checkpoints such as thermoMPNN_default.pt")
@@ -261,9 +274,17 @@ def main(argv=None):
             n_rows, stats = scan_to_file(engine, args.pdbs, chains, args.out, "ThermoMPNN", args.dataset_name, args.pick_best,
                                          args.include_cys, args.centrality, chunk_files=args.chunk_files)
             n_prot = stats.files
+        elif not args.mutations and not args.out.endswith(".npz"):
+            # N GPUs -> CSV: every rank formats its own LPT shard with the final running indices, the ranks exchange byte counts and
+            # each places its text in the one output file (dist.scan_files_to_csv): the writer scales with the ranks
+            n_rows, stats = tdist.scan_files_to_csv(engine, args.pdbs, chains, args.out, "ThermoMPNN", args.dataset_name, args.pick_best,
+                                                    args.include_cys, args.centrality, chunk_files=args.chunk_files)
+            n_prot = len(args.pdbs)
         else:
-            # N GPUs: every rank runs the pipeline on its LPT shard, ONE gather to rank 0, which writes
-            res = tdist.scan_files(engine, args.pdbs, chains, centrality=args.centrality, chunk_files=args.chunk_files)
+            # N GPUs -> binary tables / an explicit mutation list: every rank runs the pipeline on its LPT shard, ONE gather to rank
+            # 0 (over RCCL straight from the device buffer the forwards wrote), which writes
+            res = tdist.scan_files(engine, args.pdbs, chains, centrality=args.centrality, chunk_files=args.chunk_files,
+                                   device_tables=True if args.device_tables else None)
             n_prot, n_rows = len(res["names"]), 0
             err = None
             if rank == 0:
