@@ -209,13 +209,20 @@ int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const int32_t *S
 /* ---- host side: native PDB reader + packer ------------------------------------------
  * Replaces alt_parse_PDB (protein_mpnn_utils.py:183-350) + the packing of tied_featurize (:353-605) for one
  * structure: one pass over the file, all requested chains. `chains` = string of one-letter chain ids in the
- * order to concatenate them ("A", "AB", ...); NULL or "" = every chain present (A-Z, a-z, 0-9 order).
+ * order to concatenate them ("A", "AB", ...); NULL or "" = every chain present whose id is in the reference's default alphabet
+ * (A-Z, a-z, 0-9, in that order; records of other chain ids are ignored, as the reference never reads them).
  * HOST pointers here (the only entry points that are not device-side). */
 typedef struct tmpnn_pdb tmpnn_pdb_t;
 int tmpnn_pdb_parse(const char *path, const char *chains, tmpnn_pdb_t **out);
-/* n files on n_threads host threads; on failure every handle is released and outs[] is NULL. */
+/* n files on n_threads host threads; on failure every handle is released, outs[] is NULL and the message names the failing
+ * files (up to eight of them). */
 int tmpnn_pdb_parse_batch(const char *const *paths, const char *const *chains, int n, int n_threads,
                           tmpnn_pdb_t **outs);
+/* The same with a per-file result: status [n] <- TMPNN_OK or the file's error code; a failing file leaves its handle NULL and
+ * does NOT void the others (the call returns TMPNN_OK; tmpnn_last_error names the failing files) — a scan can skip or report
+ * them (the reference's loop, analysis/SSM.py:105, would stop at the first bad structure). status == NULL: as above. */
+int tmpnn_pdb_parse_batch_status(const char *const *paths, const char *const *chains, int n, int n_threads,
+                                 tmpnn_pdb_t **outs, int32_t *status);
 int64_t tmpnn_pdb_length(const tmpnn_pdb_t *p);      /* total residues L over the concatenated chains */
 int tmpnn_pdb_num_chains(const tmpnn_pdb_t *p);
 /* Any output may be NULL. X [L,4,3] fp32 with NaN -> 0, S [L] (ALPHABET index, gap -> 20), mask [L] (1 = all

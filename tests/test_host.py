@@ -158,6 +158,19 @@ def test_native_parser_batch_and_errors(tmp_path):
     with pytest.raises(TmpnnError, match="malformed"):
         native_pdb.parse_pdbs([PDB, str(bad)], ["A", "A"])
     assert native_pdb.parse_pdbs([]) == []
+    # per-file status (round 5): a bad file leaves a hole instead of voiding the batch, and the message names EVERY failing file
+    got = native_pdb.parse_pdbs([PDB, str(bad), GAP, "/nonexistent.pdb"], ["A"] * 4, skip_bad=True)
+    assert [None if g is None else len(g["seq"]) for g in got] == [194, None, 194, None]
+    with pytest.raises(TmpnnError, match=r"malformed ATOM record in .*bad\.pdb; cannot open /nonexistent\.pdb"):
+        native_pdb.parse_pdbs([PDB, str(bad), "/nonexistent.pdb"], ["A"] * 3)
+    # no chain filter = the reference's default alphabet: a malformed record under a chain id outside it (blank, punctuation) is never
+    # looked at there (protein_mpnn_utils.py:286-293 iterates A-Z, a-z, 0-9), so it must not fail the file
+    odd = tmp_path / "odd.pdb"
+    odd.write_text(open(PDB).read() + "ATOM   9999  N   ALA     1      xx.000   0.000   0.000\nATOM   9999  N   ALA *   1      yy.000   0.000   0.000\n")
+    a, b = native_pdb.parse_pdb(str(odd)), native_pdb.parse_pdb(PDB)
+    assert a["seq"] == b["seq"] and np.array_equal(a["X"], b["X"], equal_nan=True)
+    from thermompnn_amd.protein_mpnn_utils import alt_parse_PDB
+    assert alt_parse_PDB(str(odd))[0]["seq"] == a["seq"]
 
 
 def test_retrieve_best_mutants_and_rows():

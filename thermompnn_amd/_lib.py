@@ -54,6 +54,7 @@ SIGNATURES = {
     "tmpnn_ddg_head_generic": (_i, [_p, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "tmpnn_pdb_parse": (_i, [C.c_char_p, C.c_char_p, C.POINTER(_p)]),
     "tmpnn_pdb_parse_batch": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _i, _i, C.POINTER(_p)]),
+    "tmpnn_pdb_parse_batch_status": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _i, _i, C.POINTER(_p), _p]),
     "tmpnn_pdb_length": (_i64, [_p]),
     "tmpnn_pdb_num_chains": (_i, [_p]),
     "tmpnn_pdb_fill": (_i, [_p, _p, _p, _p, _p, _p, C.c_char_p, _p]),

@@ -247,6 +247,11 @@ static int parse_one(const char *path, const char *chains, tmpnn_pdb **out, std:
     const std::string want_s = chains ? chains : "";
     bool want[256] = {false};
     for (unsigned char c : want_s) want[c] = true;
+    if (want_s.empty()) {            // no filter = the reference's default chain alphabet (protein_mpnn_utils.py:286-293): records of any
+        for (int c = 'A'; c <= 'Z'; ++c) want[c] = true;      // other chain id (a blank one, punctuation) are never looked at there, so a
+        for (int c = 'a'; c <= 'z'; ++c) want[c] = true;      // malformed record in such a chain must not fail the file here
+        for (int c = '0'; c <= '9'; ++c) want[c] = true;
+    }
     std::vector<ChainAcc> acc(256);
     std::string scratch;
     bool bad = false, span = false;
@@ -273,7 +278,7 @@ static int parse_one(const char *path, const char *chains, tmpnn_pdb **out, std:
             lp = scratch.data();
             n = scratch.size();
         }
-        const LineResult r = take_atom(lp, n, want, !want_s.empty(), acc.data());
+        const LineResult r = take_atom(lp, n, want, true, acc.data());
         bad = r == kBad;
         span = r == kSpan;
     }
@@ -344,30 +349,44 @@ extern "C" int tmpnn_pdb_parse(const char *path, const char *chains, tmpnn_pdb_t
     });
 }
 
-extern "C" int tmpnn_pdb_parse_batch(const char *const *paths, const char *const *chains, int n, int n_threads,
-                                     tmpnn_pdb_t **outs) {
+// status (may be NULL) [n]: per-file result code. With it a failing file does not void the batch: its handle stays NULL, its code
+// says why, the call returns TMPNN_OK and the caller decides (skip / report); without it the first failure fails the whole batch
+// (nothing is handed out) and the message names every failing file (up to eight).
+extern "C" int tmpnn_pdb_parse_batch_status(const char *const *paths, const char *const *chains, int n, int n_threads,
+                                            tmpnn_pdb_t **outs, int32_t *status) {
     if (n < 0 || (n > 0 && (!paths || !outs))) return tm_set_error(TMPNN_E_INVALID, "pdb_parse_batch: bad argument");
     for (int i = 0; i < n; ++i) outs[i] = nullptr;
     if (n_threads < 1) n_threads = 1;
     n_threads = std::min(n_threads, std::max(n, 1));
     const int rc = tm_host_guard("pdb_parse_batch", [&]() -> int {
-        std::atomic<int> next(0), failed(-1);
+        std::atomic<int> next(0), n_failed(0);
         std::vector<std::string> errs(n);
+        std::vector<int> codes(n, TMPNN_OK);
         tm_run_pool(n_threads, [&]() {
             for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-                if (parse_one(paths[i], chains ? chains[i] : nullptr, &outs[i], &errs[i]) != TMPNN_OK) {
-                    int exp = -1;
-                    failed.compare_exchange_strong(exp, i);
-                }
+                codes[i] = parse_one(paths[i], chains ? chains[i] : nullptr, &outs[i], &errs[i]);
+                if (codes[i] != TMPNN_OK) n_failed.fetch_add(1);
             }
         });
-        const int f = failed.load();
-        if (f >= 0) return tm_set_error(TMPNN_E_INVALID, "pdb_parse_batch: %s", errs[f].c_str());
+        if (status) for (int i = 0; i < n; ++i) status[i] = codes[i];
+        if (n_failed.load() > 0) {
+            std::string msg;
+            int shown = 0;
+            for (int i = 0; i < n && shown < 8; ++i)
+                if (codes[i] != TMPNN_OK) { msg += (shown++ ? "; " : ""); msg += errs[i]; }
+            if (n_failed.load() > shown) msg += "; ... (" + std::to_string(n_failed.load()) + " files failed)";
+            tm_set_error(TMPNN_E_INVALID, "pdb_parse_batch: %s", msg.c_str());      // (readable through tmpnn_last_error in both forms)
+            if (!status) return TMPNN_E_INVALID;
+        }
         return TMPNN_OK;
     });
-    if (rc != TMPNN_OK)                       // a failed file or an exception (out of memory) in any worker: nothing is handed out
+    if (rc != TMPNN_OK)                       // a failed file (no status array) or an exception (out of memory) in any worker: nothing is handed out
         for (int i = 0; i < n; ++i) { delete outs[i]; outs[i] = nullptr; }
     return rc;
+}
+extern "C" int tmpnn_pdb_parse_batch(const char *const *paths, const char *const *chains, int n, int n_threads,
+                                     tmpnn_pdb_t **outs) {
+    return tmpnn_pdb_parse_batch_status(paths, chains, n, n_threads, outs, nullptr);
 }
 
 extern "C" int64_t tmpnn_pdb_length(const tmpnn_pdb_t *p) { return p ? (int64_t)p->S.size() : -1; }

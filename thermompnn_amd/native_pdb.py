@@ -44,8 +44,10 @@ def parse_pdb(path: str, chains=None) -> dict:
     return out
 
 
-def parse_pdbs(paths: Sequence[str], chains: Optional[Sequence] = None, n_threads: int = 0) -> List[dict]:
-    """Many structures on several host threads (the many-PDB scan of analysis/SSM.py:105)."""
+def parse_pdbs(paths: Sequence[str], chains: Optional[Sequence] = None, n_threads: int = 0, skip_bad: bool = False) -> List[Optional[dict]]:
+    """Many structures on several host threads (the many-PDB scan of analysis/SSM.py:105). ``skip_bad``: a file that fails to
+    parse yields ``None`` in its place (``tmpnn_pdb_parse_batch_status``) instead of failing the whole batch; the library's last
+    error message names the failing files (``_lib.last_error()``)."""
     lib = _lib.load()
     n = len(paths)
     if n == 0:
@@ -53,14 +55,23 @@ def parse_pdbs(paths: Sequence[str], chains: Optional[Sequence] = None, n_thread
     cp = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
     cc = (C.c_char_p * n)(*[_chains_arg(c) for c in (chains if chains is not None else [None] * n)])
     hs = (C.c_void_p * n)()
-    _lib.check(lib.tmpnn_pdb_parse_batch(cp, cc, n, n_threads or min(32, os.cpu_count() or 1), hs), "tmpnn_pdb_parse_batch")
+    nt = n_threads or min(32, os.cpu_count() or 1)
+    if skip_bad:
+        status = np.zeros(n, np.int32)
+        _lib.check(lib.tmpnn_pdb_parse_batch_status(cp, cc, n, nt, hs, status.ctypes.data), "tmpnn_pdb_parse_batch_status")
+    else:
+        _lib.check(lib.tmpnn_pdb_parse_batch(cp, cc, n, nt, hs), "tmpnn_pdb_parse_batch")
     out = []
     try:
         for i in range(n):
+            if not hs[i]:
+                out.append(None)
+                continue
             d = _unpack(lib, C.c_void_p(hs[i]))
             d["name"] = paths[i][paths[i].rfind("/") + 1:-4]
             out.append(d)
     finally:
         for i in range(n):
-            lib.tmpnn_pdb_free(C.c_void_p(hs[i]))
+            if hs[i]:
+                lib.tmpnn_pdb_free(C.c_void_p(hs[i]))
     return out

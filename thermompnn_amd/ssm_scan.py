@@ -194,6 +194,9 @@ def scan_datasets(models: dict, datasets: dict, pick_best: bool = False, include
     DATASET's wild-type string (``wt_seqs[name]``, ``name + '.pdb'`` for Megascale sets, :145-149), 'pdb' is the
     character-set-stripped structure name (:133), ``--pick_best`` / ``--include_cys`` / ``--centrality`` as there. One forward
     per protein instead of one ``model(pdb, mutations)`` call plus 20 L ``.item()`` syncs; rows by the native writer.
+    ``--centrality`` needs single-chain entries: the reference indexes the FIRST chain's neighbour counts with positions that run
+    over all chains (:129-143), so its own loop ends in an IndexError at the first position of a second chain; here the entry is
+    refused up front with a message that says so (a restriction, not a silent difference).
     -> the files written."""
     import os
     from . import native_csv
