@@ -235,6 +235,76 @@ def issue_roof(kernel, tiles, n_cus, clock_ghz, avg_ms, waves_per_simd=2):
                     "latency, s_waitcnt / s_nop are in none of them"}
 
 
+def end_to_end_sharded(eng, rank, world, n_files=None):
+    """The many-PDB scan on ALL ranks of a multi-GPU run: the same 1 024 files as ``end_to_end``, sharded by
+    LPT over the ranks — to ONE CSV through dist.scan_files_to_csv (every rank formats its own shard, byte counts exchanged, text
+    placed in the one file) and to the binary tables through dist.scan_files (one gather to rank 0, over RCCL straight from the
+    device buffers). Wall time between barriers, median of three runs. Called by every rank; -> the record on rank 0, None elsewhere.
+    The loop being sharded: analysis/SSM.py:105-176."""
+    import shutil
+    import tempfile
+    from thermompnn_amd import dist as tdist
+    from thermompnn_amd import pipeline, ssm_scan
+    from thermompnn_amd.synthetic import backbone_pdb_text
+    n_files = int(n_files or os.environ.get("TMPNN_E2E_FILES", "1024"))
+    box = [None]
+    if rank == 0:
+        try:                                                 # (a failure here must still reach the broadcast the others wait in)
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            d = tempfile.mkdtemp(prefix="tmpnn_e2e_", dir=base)
+            lens = np.random.default_rng(1).integers(64, 513, size=n_files)
+            paths = []
+            for i, L in enumerate(lens):
+                X, seq = synthetic_backbone(int(L), 1000 + i)
+                paths.append(os.path.join(d, f"syn_{i:04d}.pdb"))
+                with open(paths[-1], "w") as fh:
+                    fh.write(backbone_pdb_text(X, seq))
+            box[0] = (d, paths, int(lens.sum()), base is not None)
+        except Exception as e:                               # noqa: BLE001
+            box[0] = ("error", repr(e)[:300])
+    dist.broadcast_object_list(box, src=0)
+    if box[0][0] == "error":
+        raise RuntimeError("end_to_end_sharded: rank 0 could not write the input files: " + box[0][1])
+    d, paths, T, tmpfs = box[0]
+    chains = ["A"] * n_files
+    try:
+        def timed(fn, n=3):
+            runs = []
+            for _ in range(n):
+                dist.barrier()
+                t0 = time.perf_counter()
+                fn()
+                dist.barrier()
+                runs.append(time.perf_counter() - t0)
+            runs.sort()
+            return runs
+
+        csv_path, npz_path = os.path.join(d, "out.csv"), os.path.join(d, "out.npz")
+        to_csv = lambda ps=paths: tdist.scan_files_to_csv(eng, ps, chains[:len(ps)], csv_path, include_cys=True)
+
+        def to_npz(ps=paths):
+            res = tdist.scan_files(eng, ps, chains[:len(ps)])
+            if rank == 0:
+                ssm_scan.write_scan_npz(npz_path, res)
+        to_csv(paths[:128])                                  # warm-up (pinned slots, first launches), not timed
+        to_npz(paths[:128])
+        rc, rn = timed(to_csv), timed(to_npz)
+        if rank != 0:
+            return None
+        size = os.path.getsize(csv_path)
+        rec = lambda runs, rows: {"wall_s": runs[len(runs) // 2], "wall_s_all_runs": runs, "preds_per_s": 20 * T / runs[len(runs) // 2],
+                                  "files_per_s": n_files / runs[len(runs) // 2], "rows": rows, "reported": f"median of {len(runs)} runs"}
+        return {"files": n_files, "residues": T, "preds": 20 * T, "ranks": world, "tmpfs": tmpfs, "usable_cpus_per_rank": pipeline.usable_cpus(),
+                "to_csv": dict(rec(rc, 20 * T), output_MB=size / 1e6, writer="sharded: every rank formats its LPT shard, one file (dist.scan_files_to_csv)"),
+                "to_npz": dict(rec(rn, T), gather="one padded gather to rank 0 (device buffers under RCCL)"),
+                "workload": "BASELINE configs[2] protein set as backbone-only PDB files on tmpfs, sharded over the ranks by LPT; wall time "
+                            "between barriers from the path list to the closed output file"}
+    finally:
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(d, ignore_errors=True)
+
+
 def shader_clock_ghz(lib, device):
     """Effective shader clock right after the timed region (tmpnn_clock_probe: cycle counter against the 100 MHz reference
     under a saturated MFMA stream on all CUs)."""
@@ -1078,6 +1148,13 @@ def main():
             result["cpu_baseline"]["gpu_over_cpu"] = result["value"] / ref_cpu
             result["cpu_baseline"]["gpu_over_cpu_note"] = ("against the saturated host (all logical CPUs busy)" if sat.get("value")
                                                            else "against the best single-process thread count")
+    if grouped and dist.is_initialized() and not args.no_extras and not args.no_end_to_end and not strong:
+        try:                                                 # every rank takes part (the other ranks waited here for rank 0's extras)
+            e2e = end_to_end_sharded(eng, rank, world)
+        except Exception as e:                               # noqa: BLE001 - an extra leg must never take the bench line down
+            e2e = {"error": repr(e)[:400]}
+        if rank == 0:
+            result["end_to_end"] = e2e
     if rank == 0:
         os.write(out_fd, (json.dumps(result) + "\n").encode())
     if grouped:
