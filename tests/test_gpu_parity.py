@@ -834,7 +834,7 @@ def test_two_rank_bench_and_cli(tmp_path):
     repo = os.path.dirname(os.path.dirname(GOLDEN))
     r = _torchrun([os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--proteins-per-gpu", "2"],
                   {"TMPNN_BENCH_ONE_DEVICE": "1", "TMPNN_BENCH_BACKEND": "gloo", "TMPNN_BENCH_WARMUP_SKEW": "1",
-                   "TMPNN_BENCH_WATCHDOG": "120"})     # ranks warm up for different times: no collective may sit in that loop
+                   "TMPNN_BENCH_WATCHDOG": "120", "TMPNN_E2E_FILES": "16"})     # ranks warm up for different times: no collective may sit in that loop
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["preds_per_step"] == 2 * 2 * 256 * 20
@@ -927,7 +927,7 @@ def test_bench_line_times_the_dominant_kernel_inside_the_timed_region():
 def test_bench_self_launches_and_proves_its_ranks():
     """`python bench.py --gpus 2` with NO launcher around it (the contract command) starts itself under
     torch.distributed.run and echoes what the process group saw: world size, all_reduce(ones), one identity per rank."""
-    smoke = {"TMPNN_BENCH_ONE_DEVICE": "1", "TMPNN_BENCH_BACKEND": "gloo", "TMPNN_BENCH_WATCHDOG": "300"}
+    smoke = {"TMPNN_BENCH_ONE_DEVICE": "1", "TMPNN_BENCH_BACKEND": "gloo", "TMPNN_BENCH_WATCHDOG": "300", "TMPNN_E2E_FILES": "24"}
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     os_env_backup = dict(os.environ)
     try:
@@ -943,6 +943,10 @@ def test_bench_self_launches_and_proves_its_ranks():
     assert sorted(x["rank"] for x in c["devices"]) == [0, 1] and c["one_device_smoke_mode"] is True
     sp = d["ms_per_step_spread"]
     assert sp["n"] == 2 and sp["min"] <= sp["median"] <= sp["max"]
+    # the many-PDB scan on both ranks rides in the same line (round 5): sharded CSV writer + gather of the binary tables
+    e2e = d["end_to_end"]
+    assert e2e["ranks"] == 2 and e2e["files"] == 24 and e2e["to_csv"]["rows"] == e2e["preds"] and e2e["to_npz"]["rows"] == e2e["residues"], e2e
+    assert e2e["to_csv"]["preds_per_s"] > 0 and len(e2e["to_csv"]["wall_s_all_runs"]) == 3
 
 
 def test_rccl_runs_on_this_box_with_one_rank():
