@@ -243,6 +243,7 @@ def end_to_end_sharded(eng, rank, world, n_files=None):
     The loop being sharded: analysis/SSM.py:105-176."""
     import shutil
     import tempfile
+    import torch.distributed as dist
     from thermompnn_amd import dist as tdist
     from thermompnn_amd import pipeline, ssm_scan
     from thermompnn_amd.synthetic import backbone_pdb_text
