@@ -12,6 +12,25 @@
 
 #include "tmpnn_split.h"
 
+// GELU with SCALAR fmas (same arithmetic as gelu2, one value per instruction): v_pk_fma_f32 streams of two wavefronts share a SIMD
+// unfairly (625 vs 1115 cycles per 128 instructions, stream_kernel below), v_fma_f32 streams fairly (641 / 648)
+__device__ __forceinline__ float sfma(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+__device__ __forceinline__ float gelu1s(float x) {
+    const float t = __builtin_elementwise_minimum(fabsf(x), 5.656854249f);
+    float q = __builtin_fmaf(3.309543916e-05f, t, -7.692427171e-04f);
+    q = sfma(q, t, 8.080792133e-03f);
+    q = sfma(q, t, -5.341222090e-02f);
+    q = sfma(q, t, -4.587708865e-01f);
+    q = sfma(q, t, -1.151201730e+00f);
+    const float e = sfma(q, t, -9.999930581e-01f);
+    return __builtin_fmaf(-t, __builtin_amdgcn_exp2f(e), __builtin_elementwise_maximum(x, 0.f));
+}
+__device__ __forceinline__ f4 gelu4s(f4 v) { return f4{gelu1s(v.x), gelu1s(v.y), gelu1s(v.z), gelu1s(v.w)}; }
+
 template <int GEMM, int PRIO>
 __global__ __launch_bounds__(512, 2) void prio_kernel(const float *__restrict__ W, float *__restrict__ Y, int reps, unsigned long long *cyc) {
     using SP = SplitH2;
@@ -57,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void prio_kernel(const float *__restrict__ 
             }
         } else {
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) g[rb] = gelu4(acc[rb][0]);
+            for (int rb = 0; rb < 3; ++rb) g[rb] = PRIO == 10 ? gelu4s(acc[rb][0]) : gelu4(acc[rb][0]);
             __builtin_amdgcn_sched_barrier(0);
             if (PRIO == 5 && young) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -172,6 +191,7 @@ int main() {
     BOTH(7, "wavefronts 4-7 start 192 cycles late")
     BOTH(8, "wavefronts 4-7 start 384 cycles late")
     BOTH(9, "wavefronts 4-7: epilogue per row block")
+    BOTH(10, "GELU with scalar v_fma_f32")
     float *sink; (void)hipMalloc(&sink, 4096);
     run_stream<0, 0>(cyc, sink, "v_pk_fma_f32 x 8 regs"); run_stream<0, 1>(cyc, sink, "v_pk_fma_f32 x 8 regs");
     run_stream<1, 0>(cyc, sink, "v_fma_f32 x 8 regs"); run_stream<1, 1>(cyc, sink, "v_fma_f32 x 8 regs");

@@ -32,6 +32,11 @@
 #define S_CNDV(k)  "v_cndmask_b32_e64 %" #k ", %" #k ", 0, vcc\n\t"
 #define S_ADD(k)   "v_add_f32 %" #k ", %" #k ", %8\n\t"
 #define S_MUL(k)   "v_mul_f32 %" #k ", %" #k ", %8\n\t"
+#define S_MULHI(k) "v_mul_hi_u32 %" #k ", %" #k ", %8\n\t"
+#define S_MULLO(k) "v_mul_lo_u32 %" #k ", %" #k ", %8\n\t"
+#define S_ADD3(k)  "v_add3_u32 %" #k ", %" #k ", %8, %9\n\t"
+#define S_LSHLOR(k) "v_lshl_or_b32 %" #k ", %" #k ", 3, %8\n\t"
+#define S_ADDU(k)  "v_add_u32 %" #k ", %" #k ", %8\n\t"
 #define OPA(S) asm volatile(I8(S) : A8 : "v"(x), "v"(y), "s"(sc), "s"(sf));
 #define OPP(S) asm volatile(I8(S) : P8 : "v"(px), "v"(py), "s"(sc), "s"(sf));
 
@@ -74,6 +79,11 @@ __global__ __launch_bounds__(512, 1) void cost_kernel(int iters, int waves, unsi
             if (CLS == 19) { BODY(OPA, S_CNDV) }
             if (CLS == 20) { BODY(OPA, S_ADD) }
             if (CLS == 21) { BODY(OPA, S_MUL) }
+            if (CLS == 22) { BODY(OPA, S_MULHI) }
+            if (CLS == 23) { BODY(OPA, S_MULLO) }
+            if (CLS == 24) { BODY(OPA, S_ADD3) }
+            if (CLS == 25) { BODY(OPA, S_LSHLOR) }
+            if (CLS == 26) { BODY(OPA, S_ADDU) }
         }
         c1 = __builtin_readcyclecounter();
     }
@@ -180,6 +190,11 @@ int main() {
     run<19>("v_cndmask_b32_e64 x, 0, vcc");
     run<20>("v_add_f32");
     run<21>("v_mul_f32");
+    run<22>("v_mul_hi_u32");
+    run<23>("v_mul_lo_u32");
+    run<24>("v_add3_u32");
+    run<25>("v_lshl_or_b32");
+    run<26>("v_add_u32");
     run_chain<1, 1>(); run_chain<2, 1>(); run_chain<3, 1>(); run_chain<4, 1>(); run_chain<6, 1>(); run_chain<8, 1>();
     run_chain<1, 0>(); run_chain<2, 0>(); run_chain<3, 0>(); run_chain<4, 0>(); run_chain<6, 0>();
     return 0;
