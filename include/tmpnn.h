@@ -257,6 +257,12 @@ int tmpnn_csv_open(const char *path, int schema, tmpnn_csv_t **out);          /*
                                                                                * listing written: PICK_BEST adds its column) */
 /* The same with the header decided at once: flags = TMPNN_CSV_PICK_BEST (header with dupe_detector) | TMPNN_CSV_NO_HEADER. */
 int tmpnn_csv_open_ex(const char *path, int schema, int flags, tmpnn_csv_t **out);
+/* No file: the text goes into an anonymous mapping of `capacity` bytes (address space; pages are touched as text arrives), no
+ * header line — one rank's share of a sharded scan, kept in memory until the ranks know where each protein's text belongs
+ * (TMPNN_E_INVALID "No space left" when the listing outgrows the capacity). tmpnn_csv_mem -> the buffer and its fill; valid until
+ * tmpnn_csv_close. */
+int tmpnn_csv_open_mem(int schema, int flags, int64_t capacity, tmpnn_csv_t **out);
+const char *tmpnn_csv_mem(const tmpnn_csv_t *c, int64_t *bytes_out);
 /* The header line of a schema (flags: TMPNN_CSV_PICK_BEST) into buf -> its length, NUL-terminated (cap > length). */
 int tmpnn_csv_header(int schema, int flags, char *buf, int cap);
 /* Appends the listing of n proteins (may be called once per chunk of a scan; the running index continues). offsets [n+1]

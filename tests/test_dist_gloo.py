@@ -218,23 +218,24 @@ class _NoEngine:
     K = 48
 
 
-def _csv_worker(rank, world, port, paths, out, pick, cen, q):
+def _csv_worker(rank, world, port, paths, out, pick, cen, q, max_part_bytes=64 << 30):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from thermompnn_amd.dist import scan_files_to_csv
         rows, _ = scan_files_to_csv(_NoEngine(), paths, ["A"] * len(paths), out, "ThermoMPNN", "my set", pick_best=pick, include_cys=not pick,
-                                    centrality=cen, n_threads=2, run_pipeline=_standin_pipeline, chunk_files=2)
+                                    centrality=cen, n_threads=2, run_pipeline=_standin_pipeline, chunk_files=2, max_part_bytes=max_part_bytes)
         q.put((rank, rows, os.path.exists(f"{out}.part{rank}")))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_files,pick,cen", [(7, False, True), (7, True, False), (1, False, False)])
-def test_sharded_csv_is_byte_identical_to_the_one_writer_file(tmp_path, n_files, pick, cen):
+@pytest.mark.parametrize("n_files,pick,cen,in_memory", [(7, False, True, True), (7, True, False, True), (1, False, False, True), (5, False, False, False)])
+def test_sharded_csv_is_byte_identical_to_the_one_writer_file(tmp_path, n_files, pick, cen, in_memory):
     """dist.scan_files_to_csv on two gloo ranks (a stand-in pipeline on CPU): the one output file equals what ONE writer makes of
     the same tables in file order — running indices, --pick_best's dupe_detector column, neighbour counts — including the case
-    where a rank's shard is empty (one file, two ranks); the part files are gone afterwards."""
+    where a rank's shard is empty (one file, two ranks). A rank keeps its text in memory until the byte counts are exchanged;
+    ``in_memory=False`` forces the part-file form used for very large shards (gone afterwards)."""
     import shutil
     from conftest import GOLDEN
     from thermompnn_amd import native_csv, native_pdb
@@ -248,7 +249,7 @@ def test_sharded_csv_is_byte_identical_to_the_one_writer_file(tmp_path, n_files,
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_csv_worker, args=(r, 2, port, paths, out, pick, cen, q)) for r in range(2)]
+    procs = [ctx.Process(target=_csv_worker, args=(r, 2, port, paths, out, pick, cen, q, (64 << 30) if in_memory else 0)) for r in range(2)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=120) for _ in procs)

@@ -64,6 +64,8 @@ SIGNATURES = {
     "tmpnn_csv_open": (_i, [C.c_char_p, _i, C.POINTER(_p)]),
     "tmpnn_csv_open_ex": (_i, [C.c_char_p, _i, _i, C.POINTER(_p)]),
     "tmpnn_csv_header": (_i, [_i, _i, C.c_char_p, _i]),
+    "tmpnn_csv_open_mem": (_i, [_i, _i, _i64, C.POINTER(_p)]),
+    "tmpnn_csv_mem": (_p, [_p, C.POINTER(_i64)]),
     "tmpnn_csv_write_ssm_ex": (_i, [_p, _p, _i, _p, _i, _p, _p, _p, _p, C.c_char_p, C.c_char_p, _p, C.c_char_p, _i, _i, _p, _p]),
     "tmpnn_csv_write_ssm": (_i, [_p, _p, _i, _p, _i, _p, _p, _p, _p, C.c_char_p, C.c_char_p, _p, C.c_char_p, _i, _i]),
     "tmpnn_csv_write_listed": (_i, [_p, _p, _i, _p, _i, _p, _p, _p, C.c_char_p, C.c_char_p, _p, _i64]),

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -110,6 +111,8 @@ struct tmpnn_csv {
     int schema = 0;
     int64_t rows = 0;          // data rows written so far = the next running index
     int64_t bytes = 0;         // file offset of the next byte
+    char *mem = nullptr;       // tmpnn_csv_open_mem: the text goes into this anonymous mapping instead of a file (fd = -1)
+    int64_t mem_cap = 0;
     bool header = true;        // false: a part file of a sharded scan (no header line; tmpnn_csv_open_ex NO_HEADER)
     bool pick_header = false;  // the header line ends in ",dupe_detector" (PICK_BEST listings, SSM.py:161)
     std::string path;
@@ -128,6 +131,42 @@ static bool write_all_at(int fd, const char *p, size_t n, int64_t off) {
         p += w; n -= (size_t)w; off += w;
     }
     return true;
+}
+
+// file or memory sink
+static bool put_at(tmpnn_csv *c, const char *p, size_t n, int64_t off) {
+    if (c->mem) {
+        if (off < 0 || off + (int64_t)n > c->mem_cap) { errno = ENOSPC; return false; }
+        memcpy(c->mem + off, p, n);
+        return true;
+    }
+    return write_all_at(c->fd, p, n, off);
+}
+
+// One rank's share of a sharded scan kept in MEMORY until the ranks have exchanged their byte counts (dist.scan_files_to_csv): an
+// anonymous mapping of `capacity` bytes (address space only — pages are touched as text arrives; transparent huge pages asked
+// for), no header line. A part FILE on tmpfs would pay the file system's page allocation twice (part + final file).
+extern "C" int tmpnn_csv_open_mem(int schema, int flags, int64_t capacity, tmpnn_csv_t **out) {
+    if (!out || schema < 0 || schema > 1 || capacity <= 0) return tm_set_error(TMPNN_E_INVALID, "csv_open_mem: bad argument");
+    void *m = mmap(nullptr, (size_t)capacity, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) return tm_set_error(TMPNN_E_WORKSPACE, "csv_open_mem: cannot reserve %lld bytes: %s", (long long)capacity, strerror(errno));
+#ifdef MADV_HUGEPAGE
+    (void)madvise(m, (size_t)capacity, MADV_HUGEPAGE);
+#endif
+    const int rc = tm_host_guard("csv_open_mem", [&]() -> int {
+        std::unique_ptr<tmpnn_csv> c(new tmpnn_csv());
+        c->schema = schema; c->path = "<memory>"; c->header = false; c->pick_header = schema == 0 && (flags & TMPNN_CSV_PICK_BEST);
+        c->mem = (char *)m; c->mem_cap = capacity;
+        *out = c.release();
+        return TMPNN_OK;
+    });
+    if (rc != TMPNN_OK) munmap(m, (size_t)capacity);
+    return rc;
+}
+extern "C" const char *tmpnn_csv_mem(const tmpnn_csv_t *c, int64_t *bytes_out) {
+    if (!c || !c->mem) return nullptr;
+    if (bytes_out) *bytes_out = c->bytes;
+    return c->mem;
 }
 
 extern "C" int tmpnn_csv_open_ex(const char *path, int schema, int flags, tmpnn_csv_t **out) {
@@ -165,7 +204,7 @@ extern "C" int tmpnn_csv_close(tmpnn_csv_t *c, int64_t *rows_out, int64_t *bytes
     if (!c) return tm_set_error(TMPNN_E_INVALID, "csv_close: null handle");
     if (rows_out) *rows_out = c->rows;
     if (bytes_out) *bytes_out = c->bytes;
-    const int rc = close(c->fd);
+    const int rc = c->mem ? munmap(c->mem, (size_t)c->mem_cap) : close(c->fd);
     const std::string path = c->path;
     delete c;
     if (rc != 0) return tm_set_error(TMPNN_E_INVALID, "csv_close: %s: %s", path.c_str(), strerror(errno));
@@ -200,7 +239,7 @@ extern "C" int tmpnn_csv_write_ssm_ex(tmpnn_csv_t *c, const float *table, int ld
             return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: %s: PICK_BEST must be the same for every listing of a file", c->path.c_str());
         if (c->header) {
             const char *hdr = header_text(schema, dupe);
-            if (!write_all_at(c->fd, hdr, strlen(hdr), 0))
+            if (!put_at(c, hdr, strlen(hdr), 0))
                 return tm_set_error(TMPNN_E_INVALID, "csv_write_ssm: write to %s failed: %s", c->path.c_str(), strerror(errno));
             c->bytes = (int64_t)strlen(hdr);
         }
@@ -318,7 +357,7 @@ extern "C" int tmpnn_csv_write_ssm_ex(tmpnn_csv_t *c, const float *table, int ld
                 }
                 cv.notify_all();
                 if (bytes_out) bytes_out[i] = (int64_t)len;
-                if (len && !write_all_at(c->fd, buf.data(), len, at)) write_failed();
+                if (len && !put_at(c, buf.data(), len, at)) write_failed();
             } else {
                 const int32_t step = (int32_t)std::max<size_t>(1, kBlock / (rows_per_pos * per_row));
                 buf.resize((size_t)step * rows_per_pos * per_row + 64);
@@ -332,7 +371,7 @@ extern "C" int tmpnn_csv_write_ssm_ex(tmpnn_csv_t *c, const float *table, int ld
                 for (int32_t p0 = 0; p0 < L; p0 += step) {
                     size_t len = 0;
                     row = format(p0, std::min<int32_t>(L, p0 + step), row, &len);
-                    if (len && !write_all_at(c->fd, buf.data(), len, at)) write_failed();
+                    if (len && !put_at(c, buf.data(), len, at)) write_failed();
                     at += (int64_t)len;
                 }
                 if (bytes_out) bytes_out[i] = at - at0;
@@ -387,7 +426,7 @@ extern "C" int tmpnn_csv_write_listed(tmpnn_csv_t *c, const float *table, int ld
     int64_t at = c->bytes, row = c->rows;
     auto flush = [&]() -> bool {
         if (buf.empty()) return true;
-        const bool ok = write_all_at(c->fd, buf.data(), buf.size(), at);
+        const bool ok = put_at(c, buf.data(), buf.size(), at);
         at += (int64_t)buf.size();
         buf.clear();
         return ok;

@@ -344,7 +344,8 @@ def _copy_range(src_fd: int, dst_fd: int, src_off: int, dst_off: int, n: int) ->
 
 def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], out: str, model_name: str = "ThermoMPNN",
                       dataset: str = "custom", pick_best: bool = False, include_cys: bool = False, centrality: bool = False,
-                      group=None, k_neighbors: Optional[int] = None, n_threads: int = 0, run_pipeline=None, **pipeline_kw):
+                      group=None, k_neighbors: Optional[int] = None, n_threads: int = 0, run_pipeline=None,
+                      max_part_bytes: int = 64 << 30, **pipeline_kw):
     """PDB files -> ONE CSV in the reference's layout (analysis/SSM.py:102-176), every rank FORMATTING its own shard (round 5; until
     round 4 every table went to rank 0, which formatted the whole listing alone: one writer does 7-17 M predictions/s against
     > 100 M/s per GPU, so an 8-GPU scan to CSV ran at the one-GPU rate).
@@ -352,10 +353,11 @@ def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], 
       1. length pre-pass + LPT shards as in ``scan_files``; every rank knows every sequence, hence every protein's number of rows
          and the running index of its first row in the final listing;
       2. each rank runs the parse || forward || write pipeline on its shard; the writer thread formats chunk after chunk with the
-         FINAL running indices into a rank-local part file beside ``out`` and records the bytes of text of every protein;
+         FINAL running indices into memory (``tmpnn_csv_open_mem``; a part file beside ``out`` when the shard's text would exceed
+         ``max_part_bytes`` of address space) and records the bytes of text of every protein;
       3. ONE ``all_gather_object`` of those byte counts -> every protein's byte offset in the final file; rank 0 creates ``out``
-         (header, ftruncate to the total), every rank copies its proteins from its part file to their offsets
-         (copy_file_range), part files are removed.
+         (header, ftruncate to the total), every rank writes its proteins' text at their offsets (pwrite from the buffer /
+         copy_file_range from the part file).
     The result is byte-identical to the one-rank file (tests: world-2 gloo with a stand-in pipeline on CPU, two ranks on one GPU
     with the real engine). ``run_pipeline``: the function used as ``pipeline.scan_files`` (tests inject a CPU stand-in).
     -> (rows, stats) on every rank (rows = of the whole file)."""
@@ -380,12 +382,19 @@ def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], 
     per = 1 if pick_best else (20 if include_cys else 19)
     rows_of = [sum(c != "-" for c in info[i][1]) * per for i in range(n)]
     first_row = np.concatenate([[0], np.cumsum(rows_of)]).astype(np.int64)
+    # this rank's text stays in MEMORY (an anonymous, huge-page-backed mapping) until the byte counts are exchanged: a part file beside
+    # ``out`` pays the file system's page allocation twice, and that allocation — not the formatting — is what bounds the CSV sink
+    # (bench.py: tmpfs_write_ceiling). Address space for an upper bound of the shard's text; beyond ``max_part_bytes`` a part file.
+    name_len = lambda i: len(info[i][2])
+    bound = sum(rows_of[i] * (len(info[i][1]) + len(model_name) + len(dataset) + 2 * name_len(i) + 96) for i in shard) + (1 << 16)
+    in_memory = bound <= max_part_bytes
     part = f"{out}.part{rank}"
     nbytes = {}
     err, stats = None, None
     w = None
     try:
-        w = native_csv.CsvWriter(part, native_csv.SCHEMA_SSM, header=False, pick_best=pick_best)
+        w = (native_csv.CsvWriter(None, native_csv.SCHEMA_SSM, pick_best=pick_best, memory_capacity=bound) if in_memory else
+             native_csv.CsvWriter(part, native_csv.SCHEMA_SSM, header=False, pick_best=pick_best))
         done = [0]
 
         def sink(ch):
@@ -402,10 +411,9 @@ def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], 
             raise RuntimeError(f"the pipeline delivered {done[0]} of this rank's {len(shard)} proteins")
     except Exception as e:               # noqa: BLE001
         err = f"rank {rank}: {type(e).__name__}: {e}"
-    finally:
-        if w is not None:
-            w.close()
     try:
+        if w is not None and not in_memory:
+            w.close()
         agree_or_raise(err, group)
         parts = [None] * world
         dist.all_gather_object(parts, nbytes, group=group)
@@ -426,24 +434,45 @@ def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], 
         agree_or_raise(err, group)                           # (also the barrier behind which the file exists)
         err = None
         try:
-            src, dst = os.open(part, os.O_RDONLY), os.open(out, os.O_WRONLY)
+            jobs, pos = [], 0
+            for i in shard:                                  # consecutive proteins of the final file are placed as one range
+                if jobs and jobs[-1][1] + jobs[-1][2] == int(offs[i]) and jobs[-1][0] + jobs[-1][2] == pos:
+                    jobs[-1][2] += allb[i]
+                else:
+                    jobs.append([pos, int(offs[i]), allb[i]])
+                pos += allb[i]
+            blk = 16 << 20                                   # (ranges cut into blocks so that every writer thread has work)
+            jobs = [[a + k, b + k, min(blk, m - k)] for a, b, m in jobs for k in range(0, m, blk)]
+            dst = os.open(out, os.O_WRONLY)
+            src = -1 if in_memory else os.open(part, os.O_RDONLY)
             try:
-                jobs, pos = [], 0
-                for i in shard:                              # consecutive proteins of the final file are copied as one range
-                    if jobs and jobs[-1][1] + jobs[-1][2] == int(offs[i]) and jobs[-1][0] + jobs[-1][2] == pos:
-                        jobs[-1][2] += allb[i]
-                    else:
-                        jobs.append([pos, int(offs[i]), allb[i]])
-                    pos += allb[i]
-                with ThreadPoolExecutor(max_workers=max(1, min(nt, 8))) as ex:
-                    list(ex.map(lambda j: _copy_range(src, dst, j[0], j[1], j[2]), jobs))
+                if in_memory:
+                    text = w.memory()
+                    view = memoryview(text)
+
+                    def place(j):
+                        a, b, m = j
+                        while m > 0:
+                            k = os.pwrite(dst, view[a:a + m], b)
+                            a, b, m = a + k, b + k, m - k
+                else:
+                    place = lambda j: _copy_range(src, dst, j[0], j[1], j[2])
+                with ThreadPoolExecutor(max_workers=max(1, min(nt, 16))) as ex:
+                    list(ex.map(place, jobs))
             finally:
-                os.close(src)
                 os.close(dst)
+                if src >= 0:
+                    os.close(src)
         except OSError as e:
             err = f"rank {rank}: {e}"
         agree_or_raise(err, group)
     finally:
+        if w is not None and in_memory:
+            try:
+                view = text = None                           # (the mapping goes away with the writer)
+                w.close()
+            except Exception:                                # noqa: BLE001
+                pass
         try:
             os.remove(part)
         except OSError:

@@ -47,14 +47,27 @@ def format_double(v: float) -> str:
 class CsvWriter:
     """One output file; ``write_ssm`` / ``write_listed`` append chunks (the running index continues)."""
 
-    def __init__(self, path: str, schema: int = SCHEMA_SSM, header: bool = True, pick_best: bool = False):
+    def __init__(self, path: Optional[str], schema: int = SCHEMA_SSM, header: bool = True, pick_best: bool = False,
+                 memory_capacity: int = 0):
         """``header=False``: a part file of a sharded scan (no header line); ``pick_best``: the header carries the reference's
-        extra ``dupe_detector`` column at once (otherwise the first ``write_ssm`` decides)."""
+        extra ``dupe_detector`` column at once (otherwise the first ``write_ssm`` decides). ``path=None`` + ``memory_capacity``: no
+        file — the text is kept in an anonymous buffer of that many bytes of address space (``memory()``), header-less."""
         self.lib = _lib.load()
         self.h = C.c_void_p()
         flags = (0 if header else NO_HEADER) | (PICK_BEST if pick_best else 0)
-        _lib.check(self.lib.tmpnn_csv_open_ex(os.fsencode(path), int(schema), flags, C.byref(self.h)), "tmpnn_csv_open")
+        if path is None:
+            _lib.check(self.lib.tmpnn_csv_open_mem(int(schema), flags, int(memory_capacity), C.byref(self.h)), "tmpnn_csv_open_mem")
+        else:
+            _lib.check(self.lib.tmpnn_csv_open_ex(os.fsencode(path), int(schema), flags, C.byref(self.h)), "tmpnn_csv_open")
         self.path, self.rows, self.bytes = path, 0, 0
+
+    def memory(self):
+        """-> a ctypes char array over the text written so far (memory writers only; valid until ``close``)."""
+        n = C.c_int64()
+        p = self.lib.tmpnn_csv_mem(self.h, C.byref(n))
+        if not p:
+            raise ValueError("not a memory writer")
+        return (C.c_char * n.value).from_address(p)
 
     def write_ssm(self, table: np.ndarray, offsets: np.ndarray, seqs: Sequence, names: Sequence,
                   neighbors: Optional[np.ndarray] = None, model: str = "ThermoMPNN", dataset: str = "custom",
