@@ -84,3 +84,28 @@ def test_committed_isa_counts_belong_to_the_committed_kernel_sources():
     assert ir["tiles_per_cu"] == 64 and 0.2 < ir["frac_overlap"] < ir["frac_hetero"] < ir["frac_serial"] < 1.0
     assert abs(ir["t_serial_us"] - (ir["t_valu_us"] + ir["t_mfma_us"])) < 1e-9 and ir["t_overlap_us"] == max(ir["t_valu_us"], ir["t_mfma_us"])
     assert 2.5 <= ir["mean_valu_cost_cycles"] <= 6.6        # priced per opcode (tools/probe/valu_cost_probe.hip)
+
+
+def test_tracked_round_evidence_is_not_empty_and_belongs_to_these_kernels():
+    """`profiles/r04_parity_worst_errors.json` was committed as `{}` while DESIGN quoted it. Every tracked JSON of the
+    newest round under profiles/ must hold something, the parity record must be the GPU suite's (>= 150 entries), and the files that
+    are stamped with the kernel-source hash (ISA counts, PMC traffic) must have been made from the sources in this tree."""
+    import glob
+    import json
+    import re
+    import bench
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_*.json")))
+    newest = max(re.match(r"r(\d+)_", os.path.basename(f)).group(1) for f in files)
+    mine = [f for f in files if os.path.basename(f).startswith(f"r{newest}_")]
+    assert len(mine) >= 8, mine
+    for f in mine:
+        d = json.load(open(f))
+        assert d, f"{f} is empty"
+    worst = json.load(open(os.path.join(REPO, "profiles", f"r{newest}_parity_worst_errors.json")))
+    assert len(worst) >= 150 and all("ratio" in v for v in worst.values()) and max(v["ratio"] for v in worst.values()) <= 1.0
+    stamp = bench.kernel_source_stamp()
+    assert json.load(open(os.path.join(REPO, "profiles", f"r{newest}_isa_counts.json")))["source_stamp"] == stamp
+    assert json.load(open(os.path.join(REPO, "profiles", f"r{newest}_pmc_traffic.json")))["kernel_source_stamp"] == stamp, \
+        "profiles/*_pmc_traffic.json was measured on other kernel sources: rerun tools/pmc_traffic.sh (tools/measure_round.sh)"
+    line = json.load(open(os.path.join(REPO, "profiles", f"r{newest}_bench_full.json")))
+    assert line["roofline"]["traffic"] and line["roofline"]["issue"]["frac_overlap"] < line["roofline"]["issue"]["frac_serial"] < 1.0
