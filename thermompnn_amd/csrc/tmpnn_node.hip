@@ -153,6 +153,24 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
                 v[it] = ld4(a.Ssum + g);
                 hvv[it] = ld4(a.h_in + g);
             }
+            // the tile's per-row scalars (neighbour count, mask, the two sequence-table indices) are requested HERE, all four at once and
+            // unconditionally (absent tables read a dummy), behind the rows and in front of their first use: round 5 found them as three
+            // dependent load -> wait -> LDS-store groups of wavefront 0 in front of the tile's first barrier (one L2 round trip each, with
+            // the other seven wavefronts waiting)
+            const int rr = tid < ROWS ? tid : 0;                 // (ROWS = 48 is not a power of two)
+            const bool okr = r0 + rr < a.T;
+            const int gr = okr ? r0 + rr : r0;
+            const bool ha0 = has0 && a.proj[0].add_tab != nullptr, ha1 = has1 && a.proj[1].add_tab != nullptr;
+            const int32_t *ai0 = ha0 ? a.proj[0].add_idx : reinterpret_cast<const int32_t *>(a.cnt);
+            const int32_t *ai1 = ha1 ? a.proj[1].add_idx : reinterpret_cast<const int32_t *>(a.cnt);
+            float cv = 0.f, mv = 0.f;
+            int i0 = 0, i1 = 0;
+            if (tid < ROWS) {
+                cv = a.cnt[gr];
+                mv = a.mask[gr];
+                i0 = ai0[gr];
+                i1 = ai1[gr];
+            }
 #pragma unroll
             for (int it = 0; it < NRB; ++it) {
                 const int row = 16 * it + (tid >> 5), c = tid & 31;
@@ -161,17 +179,13 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
                 store_split<SP, ROWS>(pA, row, c, ok ? v[it] : z4);
                 st4(tB + chunk_off(row, c), ok ? hvv[it] : z4);
             }
-        }
-        mark();
-        if (tid < ROWS) {
-            const bool ok = r0 + tid < a.T;
-            const int g = ok ? r0 + tid : r0;
-            const float cv = a.cnt[g], mv = a.mask[g];
-            s_cnt[tid] = ok ? cv : 0.f;
-            s_mask[tid] = ok ? mv : 0.f;
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-                if (a.proj[k].P != nullptr && a.proj[k].add_tab != nullptr) s_aidx[k][tid] = ok ? a.proj[k].add_idx[g] : 0;
+            mark();
+            if (tid < ROWS) {
+                s_cnt[tid] = okr ? cv : 0.f;
+                s_mask[tid] = okr ? mv : 0.f;
+                if (ha0) s_aidx[0][tid] = okr ? i0 : 0;
+                if (ha1) s_aidx[1][tid] = okr ? i1 : 0;
+            }
         }
         __syncthreads();
         mark();

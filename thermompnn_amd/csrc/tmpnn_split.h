@@ -34,7 +34,9 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 #define TM_EDGE_PF 2        // edge update: 0.339 ms at 0, 0.329 at 1, 0.323 at 2, 0.326 at 3-4 (round 2)
 #define TM_MSG_PF 3         // message kernels
 #define TM_NODE_PF 3        // node update, tall tile
-#define TM_NODE_DEEP_D 3    // node update, one 16-row tile per workgroup: fragment images in flight ahead of the GEMM unit being computed
+#define TM_NODE_DEEP_D 2    // node update, one 16-row tile per workgroup: fragment images in flight ahead of the GEMM unit being computed. Round 5: 2, not 3
+                            // — at 3 the two-projection form was 4 VGPRs over its budget (hipcc spilled a freshly LOADED bias vector: `s_waitcnt
+                            // vmcnt(0); scratch_store` in the middle of the prologue's load cluster); 15.0 against 15.6 us per launch, L = 256
 #define TM_NODE_DEEP_PF 2   // ... its B-fragment prefetch distance (a 16-row GEMM has 4 steps; 3 would hold all four at once: 8 more VGPRs)
 #ifndef TM_PROF_TID
 #define TM_PROF_TID 0       // thread of workgroup 0 the TMPNN_*_PROF phase timers read (448 = wavefront 7, lowest issue priority)
