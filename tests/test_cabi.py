@@ -103,3 +103,27 @@ def test_shipped_library_has_no_environment_switches():
     assert not [n for n in names if n in shipped]
     assert all(n in debug for n in names)
     assert b"phases (" not in shipped and b"phases (" in debug          # the timers' fprintf formats
+
+
+def test_shipped_kernels_have_one_form_and_no_ablations():
+    """the lab is out of the product sources. Timing ablations (TM_ABL_*: results wrong by construction) compile
+    only with -DTMPNN_DEBUG_BUILD — the shipped flags refuse them with an #error —, the dead kernel-form switches of rounds 1-4 are
+    gone from the sources, and no 'TM_ABL' string is in the shipped library."""
+    import glob
+    import subprocess
+    from thermompnn_amd import _lib, build
+    csrc = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc")
+    text = {f: open(f).read() for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))}
+    for gone in ("TM_EDGE_UNROLL2", "TM_SETPRIO", "TM_SPLIT_MIX", "TM_MSG_PFD", "TM_EDGE_Y_ALIAS", "TM_GELU_FORM", "TM_GELU_ASM", "TM_MSG_TOUCH"):
+        assert not [f for f, t in text.items() if gone in t], gone
+    assert b"TM_ABL" not in open(_lib.LIB_PATH, "rb").read()
+    assert set(os.path.basename(f) for f in text) >= {"tmpnn_edge.hip", "tmpnn_msg.hip", "tmpnn_edge_msg.hip", "tmpnn_node.hip"}
+    assert max(t.count("\n") for t in text.values()) < 1300              # (round 4: one 1 735-line file held seven kernels)
+    # an ablation without the debug define does not compile (preprocessor only: no GPU, a second)
+    hipcc = build._hipcc()
+    src = os.path.join(csrc, "tmpnn_msg.hip")
+    flags = [*build.FLAGS, *build.FILE_FLAGS["tmpnn_msg.hip"], "--offload-device-only", "-E", "-o", os.devnull, src]
+    bad = subprocess.run([hipcc, *flags, "-DTM_ABL_NOGELU=1"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "TMPNN_DEBUG_BUILD" in bad.stderr
+    ok = subprocess.run([hipcc, *flags, "-DTM_ABL_NOGELU=1", "-DTMPNN_DEBUG_BUILD"], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-500:]
