@@ -9,7 +9,7 @@ cd $R
 timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x > $O/${TAG}_gpu_parity.log 2>&1; tail -3 $O/${TAG}_gpu_parity.log
 cp $O/parity_worst_errors.json $O/${TAG}_parity_worst_errors.json
 python tools/isa_counts.py $O/${TAG}_isa_counts.json > /dev/null 2>&1
-(tools/probe/valu_cost_probe; tools/probe/hetero_probe; tools/probe/ilv_probe_asm1; tools/probe/spec_probe_pf2; tools/probe/prio_probe) > $O/${TAG}_probes.txt 2>&1
+(tools/probe/valu_cost_probe; tools/probe/hetero_probe; tools/probe/ilv_probe_asm1; tools/probe/spec_probe_pf2; tools/probe/prio_probe; tools/probe/helper_probe) > $O/${TAG}_probes.txt 2>&1
 bash tools/pmc_traffic.sh > $O/${TAG}_pmc_traffic.log 2>&1
 cp $O/pmc_traffic/pmc_traffic.json $O/${TAG}_pmc_traffic.json; cp $O/pmc_traffic/FETCH_SIZE_per_kernel.csv $O/${TAG}_pmc_FETCH_SIZE_per_kernel.csv; cp $O/pmc_traffic/WRITE_SIZE_per_kernel.csv $O/${TAG}_pmc_WRITE_SIZE_per_kernel.csv
 cp $O/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json   # bench.py reads the stamped file: PMC pass first, so the bench line of THIS call carries traffic
