@@ -51,6 +51,15 @@ int main(int argc, char **argv) {
             printf("%d -1 -1 0\n", rc);
         }
     }
+    {   // the per-file status form: every file gets a code, a failing one leaves a NULL handle and does not void the others
+        std::vector<tmpnn_pdb_t *> hs2(paths.size() + 1, nullptr);
+        std::vector<int32_t> st(paths.size() + 1, 12345);
+        if (tmpnn_pdb_parse_batch_status(paths.data(), nullptr, (int)paths.size(), threads, hs2.data(), st.data()) != TMPNN_OK) return 6;
+        for (size_t i = 0; i < paths.size(); ++i) {
+            if ((st[i] == TMPNN_OK) != (hs2[i] != nullptr)) return 6;
+            if (hs2[i]) { use(hs2[i]); tmpnn_pdb_free(hs2[i]); }
+        }
+    }
     std::vector<tmpnn_pdb_t *> hs(paths.size() + 1, nullptr);
     const int rc = tmpnn_pdb_parse_batch(paths.data(), nullptr, (int)paths.size(), threads, hs.data());
     // a failing batch releases every handle; parse the survivors one by one for the pack / writer legs
@@ -85,6 +94,27 @@ int main(int argc, char **argv) {
                                                           tri.data(), (int64_t)tri.size() / 3) != TMPNN_OK) return 4;
                 int64_t rows = 0, bytes = 0;
                 if (tmpnn_csv_close(c, &rows, &bytes) != TMPNN_OK || rows < 0 || bytes <= 0) return 4;
+                // the same listing into the MEMORY sink of a sharded scan: explicit running indices, bytes per protein, and the sum of those
+                // bytes must be the buffer's fill; then a capacity that is too small must fail cleanly (no write beyond the mapping)
+                if (schema == 0) {
+                    std::vector<int64_t> first(n), nbytes(n, -1);
+                    for (int i = 0; i < n; ++i) first[i] = 1000000007LL * (i + 1);
+                    tmpnn_csv_t *mc = nullptr;
+                    if (tmpnn_csv_open_mem(schema, flags, bytes + 4096, &mc) != TMPNN_OK) return 5;
+                    if (tmpnn_csv_write_ssm_ex(mc, table.data(), 21, off.data(), n, seqs.data(), nullptr, names.data(), flags & 1 ? nb.data() : nullptr, "Thermo,MPNN",
+                                               "a \"quoted\" set", nullptr, "A", flags, threads, first.data(), nbytes.data()) != TMPNN_OK) return 5;
+                    int64_t fill = 0, sum = 0;
+                    const char *mem = tmpnn_csv_mem(mc, &fill);
+                    for (int i = 0; i < n; ++i) sum += nbytes[i];
+                    if (!mem || fill != sum || (fill > 0 && mem[fill - 1] != '\n')) return 5;
+                    if (tmpnn_csv_close(mc, nullptr, nullptr) != TMPNN_OK) return 5;
+                    if (fill > 64) {
+                        if (tmpnn_csv_open_mem(schema, flags, fill / 2, &mc) != TMPNN_OK) return 5;
+                        if (tmpnn_csv_write_ssm_ex(mc, table.data(), 21, off.data(), n, seqs.data(), nullptr, names.data(), nullptr, "m", "d", nullptr, "A", flags, threads,
+                                                   nullptr, nullptr) == TMPNN_OK) return 5;
+                        if (tmpnn_csv_close(mc, nullptr, nullptr) != TMPNN_OK) return 5;
+                    }
+                }
             }
     }
     for (tmpnn_pdb_t *h : ok) tmpnn_pdb_free(h);
