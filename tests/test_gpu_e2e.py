@@ -101,10 +101,28 @@ def test_pipeline_reruns_an_overflowing_chunk(tmp_path, synthetic_weights):
         warnings.simplefilter("always")
         _, stats = ssm_scan.scan_to_file(Engine(W, "cuda:0", 48, precision="f16x2"), paths, ch, str(tmp_path / "got.npz"), chunk_files=3)
     assert stats.reruns == stats.chunks >= 2 and any("bf16x3" in str(w.message) for w in rec)
-    np.testing.assert_array_equal(np.load(tmp_path / "got.npz")["ddg"], np.load(tmp_path / "want.npz")["ddg"])
+    want = np.load(tmp_path / "want.npz")["ddg"]
+    np.testing.assert_array_equal(np.load(tmp_path / "got.npz")["ddg"], want)
     with pytest.raises(TmpnnRangeError):
         ssm_scan.scan_to_file(Engine(W, "cuda:0", 48, precision="f16x2", retry_precision=None), paths, ch,
                               str(tmp_path / "strict.npz"), chunk_files=3)
+    # the device-table form of the pipeline (what a multi-rank scan gathers over RCCL, round 5): the tables stay on the GPU, the sink
+    # gets no host copy, and a rerun writes the chunk's rows of the SAME device buffer — on a side stream, so that the rerun's use of
+    # the caller's stream (not the writer thread's default one) is exercised
+    from thermompnn_amd import pipeline
+    dev_table = torch.full((want.shape[0] + 7, 21), float("nan"), device="cuda:0")
+    seen = []
+    side = torch.cuda.Stream()
+    with warnings.catch_warnings(record=True) as rec2, torch.cuda.stream(side):
+        warnings.simplefilter("always")
+        st = pipeline.scan_files(Engine(W, "cuda:0", 48, precision="f16x2"), paths, ch, lambda c: seen.append((c.table is None, c.row0, c.T)),
+                                 chunk_files=3, device_table=dev_table)
+        side.synchronize()
+    assert st.reruns == st.chunks >= 2 and all(t for t, _, _ in seen) and [r for _, r, _ in seen] == list(np.cumsum([0] + [T for _, _, T in seen])[:-1])
+    np.testing.assert_array_equal(dev_table[:want.shape[0]].cpu().numpy(), want)
+    assert torch.isnan(dev_table[want.shape[0]:]).all()
+    with pytest.raises(ValueError, match="device_table holds"):
+        pipeline.scan_files(Engine(synthetic_weights, "cuda:0", 48), paths, ch, None, device_table=dev_table[:10])
 
 
 def test_custom_inference_fast_path_equals_the_reference_shaped_path(tmp_path):
