@@ -158,8 +158,11 @@ def valu_cost(op):
 
 
 ISA_SYMBOLS = {   # bench kernel name -> the instantiation the bench batch launches (f16x2, images, 32-bit gather offsets)
-    "enc_edge": "enc_edge8_rp_kernelI7SplitH2Lb0ELb1E", "enc_msg": "msg8_rp_kernelI7SplitH2Lb0ELb0ELb1E",
-    "dec_msg": "msg8_rp_kernelI7SplitH2Lb1ELb0ELb1E"}
+    "enc_edge": "enc_edge8_rp_kernelI7SplitH2Lb0ELb1E", "enc_msg": "msg8_wave_kernelILb0ELb1ELb0E",
+    "dec_msg": "msg8_wave_kernelILb1ELb1ELb0E"}
+# wavefront-trips of the counted loop per tile (= one residue's 48 x 128 edge block): the 8-wavefront kernels run ONE trip in each of a
+# workgroup's 8 wavefronts, the wavefront-per-residue message kernel THREE trips (16-row blocks) in one wavefront
+ISA_WAVE_TRIPS = {"enc_edge": 8, "enc_msg": 3, "dec_msg": 3}
 # (not the featurizer: its tile loop contains run-time loops — 9.4 trips of the Gaussian loop per tile — so static counts of one
 #  trip understate what a wavefront issues; the per-edge kernels' tile loops are straight-line code)
 
@@ -189,7 +192,7 @@ def isa_counts(kernel):
     return None
 
 
-def issue_roof(kernel, tiles, n_cus, clock_ghz, avg_ms, waves_per_simd=2):
+def issue_roof(kernel, tiles, n_cus, clock_ghz, avg_ms):
     """The THIRD roof: instruction issue, as a BRACKET. One tile (= one residue's 48 x 128 edge block) is one
     trip of the persistent loop in each of the workgroup's 8 wavefronts, 2 per SIMD. Per SIMD and tile the two wavefronts issue
     t_valu = 2 x sum(count x cost of the opcode) cycles of VALU work and t_mfma = 2 x sum(MFMA x 16) cycles of matrix-pipe work
@@ -212,6 +215,7 @@ def issue_roof(kernel, tiles, n_cus, clock_ghz, avg_ms, waves_per_simd=2):
     else:       # a counts file without the opcode histogram: class costs
         cyc_valu = VALU_COST_DEFAULT * c.get("valu", 0) + VALU_COST_PACKED * c.get("valu_packed", 0) + VALU_COST_TRANS * c.get("valu_trans", 0)
     tiles_per_cu = -(-tiles // n_cus)
+    waves_per_simd = ISA_WAVE_TRIPS.get(kernel, 8) / 4.0      # wavefront-trips per tile and SIMD
     to_s = lambda cyc: tiles_per_cu * waves_per_simd * cyc / (clock_ghz * 1e9)
     t_valu, t_mfma = to_s(cyc_valu), to_s(cyc_mfma)
     t_serial, t_overlap = t_valu + t_mfma, max(t_valu, t_mfma)
@@ -222,11 +226,11 @@ def issue_roof(kernel, tiles, n_cus, clock_ghz, avg_ms, waves_per_simd=2):
             "t_valu_us": t_valu * 1e6, "t_mfma_us": t_mfma * 1e6,
             "cycles_per_simd_tile": {"valu": waves_per_simd * cyc_valu, "mfma": waves_per_simd * cyc_mfma,
                                      "measured": avg_ms * 1e-3 * clock_ghz * 1e9 / tiles_per_cu},
-            "counts_per_wavefront_tile": {"mfma": sum(mf.values()), "valu": c.get("valu", 0), "valu_packed": c.get("valu_packed", 0),
+            "counts_per_wavefront_trip": {"mfma": sum(mf.values()), "valu": c.get("valu", 0), "valu_packed": c.get("valu_packed", 0),
                                           "valu_trans": c.get("valu_trans", 0), "salu": c.get("salu", 0), "lds": c.get("lds", 0),
                                           "vmem": c.get("vmem", 0), "barriers": c.get("barrier", 0), "waitcnt": c.get("waitcnt", 0)},
             "mean_valu_cost_cycles": cyc_valu / n_valu if n_valu else None,
-            "tiles_per_cu": tiles_per_cu, "waves_per_simd": waves_per_simd, "clock_GHz": clock_ghz,
+            "tiles_per_cu": tiles_per_cu, "wavefront_trips_per_tile": ISA_WAVE_TRIPS.get(kernel, 8), "clock_GHz": clock_ghz,
             "vgprs": c.get("vgprs"), "lds_bytes": c.get("lds_bytes"), "counts_from": c.get("file"), "symbol": c.get("symbol"),
             "note": "bracket of the instruction-issue bound: static counts of the shipped code object's tile loop (tools/isa_counts.py) x "
                     "per-opcode issue cost with two wavefronts per SIMD (tools/probe/valu_cost_probe.hip: 2.5-3.8 cycles, transcendental / "
@@ -319,6 +323,32 @@ def shader_clock_ghz(lib, device):
         torch.cuda.synchronize()
         o = out.cpu().view(-1, 2).double()
         return float(o[:, 0].mean() / (o[:, 1].mean() / 100e6) / 1e9)
+    except Exception:
+        return None
+
+
+def clock_under_load_ghz(lib, device, step, ms_per_step):
+    """The clock the chip keeps while the timed workload runs (tmpnn_clock_monitor: one sleeping wavefront on a side stream reads the
+    shader cycle counter against the 100 MHz reference for ~60 % of a second, un-timed, run of steps). Round 5: 2.03-2.1 GHz under
+    the f16x2 pipeline against 2.35-2.4 GHz for the same chip idle or under an fp32-MFMA loop — the forward is power-limited, and
+    every cycle figure of the issue bracket has to be priced with THIS clock."""
+    try:
+        n = max(12, int(60.0 / max(ms_per_step, 1e-3)))                # ~60 ms of forwards
+        iters = max(1000, int(0.6 * n * ms_per_step * 1e-3 * 2.0e9 / 8128))
+        out = torch.zeros(2, dtype=torch.int64, device=device)
+        side = torch.cuda.Stream(device=device)
+        for _ in range(4):
+            step(False)
+        ev = torch.cuda.Event()
+        ev.record()
+        side.wait_event(ev)
+        if lib.tmpnn_clock_monitor(iters, C.c_void_p(out.data_ptr()), C.c_void_p(side.cuda_stream)) != 0:
+            return None
+        for _ in range(n):
+            step(False)
+        torch.cuda.synchronize()
+        cyc, ticks = (float(v) for v in out.cpu())
+        return cyc / (ticks / 100e6) / 1e9 if ticks > 0 else None
     except Exception:
         return None
 
@@ -941,7 +971,10 @@ def main():
     lib.tmpnn_profile_select(None)
     eng.check_last_status()                              # a range / max_len problem in the timed work is an error, not a number
     step_spread = spread(events)
-    clock_ghz = shader_clock_ghz(lib, device) if rank == 0 else None
+    clock_probe_ghz = shader_clock_ghz(lib, device) if rank == 0 else None
+    clock_ghz = clock_under_load_ghz(lib, device, step, dt / args.steps * 1e3) if rank == 0 and not grouped else None
+    if clock_ghz is None:
+        clock_ghz = clock_probe_ghz
     n_cus = torch.cuda.get_device_properties(device).multi_processor_count
 
     if strong:
@@ -1032,6 +1065,10 @@ def main():
                 "bound": rf["bound"], "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                 "traffic": pmc_traffic(dom, T), "kernel": dom, "avg_launch_ms": kern[dom]["avg_ms"],
                 "issue": issue_roof(dom, T, n_cus, clock_ghz, kern[dom]["avg_ms"]) if mode == "f16x2" and not strong else None,
+                "clock_GHz": {"under_this_workload": clock_ghz, "fp32_mfma_probe": clock_probe_ghz,
+                              "note": "under_this_workload: tmpnn_clock_monitor on a side stream beside an un-timed run of the same steps — "
+                                      "the f16x2 pipeline is power-limited (round 5: 2.03 GHz inside a message kernel, 2.38 GHz with its "
+                                      "MFMAs removed); the issue bracket's cycles are priced with it"},
                 "algorithmic_bytes_per_launch": rf["hbm"]["bytes_per_launch"], "flops_per_launch": rf["mfma"]["flops_per_launch"],
                 "t_hbm_roof_us": rf["t_hbm_us"], "t_mfma_roof_us": rf["t_mfma_us"],
                 "hbm": rf["hbm"], "mfma": rf["mfma"],
@@ -1041,9 +1078,9 @@ def main():
                          (f"{BF16_MFMA_PEAK_TFLOPS:.0f} / {terms} TFLOP/s (the kernel runs them as {terms}-term {mode} split products on the "
                           "16-bit matrix cores)" if terms else "the 157.3 TFLOP/s fp32 matrix pipe") +
                          "; `bound` is the roof with the larger time, `frac` is against it; `issue` is the third roof as a bracket — the "
-                         "VALU and matrix-pipe time of the shipped code object's tile loop at the measured clock, serialised "
-                         "(frac_serial) or perfectly overlapped (frac_overlap); the kernel's lock-step GEMM / epilogue phases put it "
-                         "near the serial end"),
+                         "VALU and matrix-pipe time of the shipped code object's tile loop at the clock measured UNDER THIS WORKLOAD, "
+                         "serialised (frac_serial) or perfectly overlapped (frac_overlap); the chip runs this pipeline power-limited "
+                         "(clock_GHz), which is why pipe times add whatever the schedule"),
                 "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r*_pmc_traffic.json; null when no file was measured on these kernel sources)",
                 "timed_with": "hipEvent pairs on the launch stream around this kernel's launches inside the timed region"}
             result["kernels"] = kern

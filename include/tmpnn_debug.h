@@ -35,6 +35,12 @@ int tmpnn_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_t
  * `sink` (>= 256 floats) keeps the result live. */
 int tmpnn_clock_probe(int blocks, int iters, uint64_t *out, float *sink, tmpnn_stream_t stream);
 
+/* The clock the chip keeps under whatever runs beside this call: ONE sleeping wavefront (no LDS, it fits beside every kernel of the
+ * library) reads the shader cycle counter and the 100 MHz reference around iters x s_sleep 127 (about 8 100 cycles each). Launch it on a
+ * side stream while the forward runs on another: out[0] = shader cycles, out[1] = 100 MHz ticks. (The f16x2 pipeline runs power-limited:
+ * 2.03-2.1 GHz against the 2.4 GHz the idle chip reports — bench.py prices its cycle figures with THIS clock.) */
+int tmpnn_clock_monitor(int iters, uint64_t *out, tmpnn_stream_t stream);
+
 /* n dependent launches of a do-nothing kernel (grid x block, lds_bytes of dynamic LDS; dirty_floats > 0: each launch writes that
  * many floats of buf): this box's price of a kernel boundary, to compare with the gaps of the real forward (tools/gap_probe.py). */
 int tmpnn_launch_probe(int n, int grid, int block, int lds_bytes, float *buf, int dirty_floats, tmpnn_stream_t stream);

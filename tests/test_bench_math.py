@@ -84,6 +84,15 @@ def test_committed_isa_counts_belong_to_the_committed_kernel_sources():
     assert ir["tiles_per_cu"] == 64 and 0.2 < ir["frac_overlap"] < ir["frac_hetero"] < ir["frac_serial"] < 1.0
     assert abs(ir["t_serial_us"] - (ir["t_valu_us"] + ir["t_mfma_us"])) < 1e-9 and ir["t_overlap_us"] == max(ir["t_valu_us"], ir["t_mfma_us"])
     assert 2.5 <= ir["mean_valu_cost_cycles"] <= 6.6        # priced per opcode (tools/probe/valu_cost_probe.hip)
+    assert ir["wavefront_trips_per_tile"] == 8
+    # the message kernels of the bench batch: one wavefront per residue, three 16-row blocks = three trips of the counted loop, every
+    # trip the whole chain for 16 rows x 128 columns (2 GEMMs x 32 units x 3 partial products)
+    for k in ("enc_msg", "dec_msg"):
+        cm = bench.isa_counts(k)
+        assert cm is not None and "msg8_wave_kernel" in cm["symbol"] and cm["mfma:v_mfma_f32_16x16x32_f16"] == 192 and cm.get("barrier", 0) == 0
+        im = bench.issue_roof(k, 16384, 256, 2.05, 0.19)
+        assert im["wavefront_trips_per_tile"] == 3 and abs(im["cycles_per_simd_tile"]["mfma"] - 0.75 * 192 * 16) < 1e-6
+        assert 0.2 < im["frac_overlap"] < im["frac_serial"] < 1.0
 
 
 def test_tracked_round_evidence_is_not_empty_and_belongs_to_these_kernels():

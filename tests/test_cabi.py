@@ -46,8 +46,8 @@ def test_tensor_table_matches_python_state_dict_order():
     assert lib.tmpnn_version() == 200
     assert lib.tmpnn_workspace_bytes(256) > 256 * 48 * 128 * 4
     tables = (66 * 128 + 3 * 21 * 128 + 384 * 384) * 4
-    assert lib.tmpnn_weights_packed_bytes() == tables + 110 * 65536
-    assert lib.tmpnn_weights_packed_bytes_p(b"f16x2") == tables + 110 * 65536            # fragment images: f16x2 handles only
+    assert lib.tmpnn_weights_packed_bytes() == tables + 122 * 65536
+    assert lib.tmpnn_weights_packed_bytes_p(b"f16x2") == tables + 122 * 65536            # fragment images: f16x2 handles only
     assert lib.tmpnn_weights_packed_bytes_p(b"bf16x3") == lib.tmpnn_weights_packed_bytes_p(b"fp32") == tables
     assert lib.tmpnn_weights_packed_bytes_p(b"fp64") == 0
 

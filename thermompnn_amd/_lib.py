@@ -80,6 +80,7 @@ DEBUG_SIGNATURES = {
     "tmpnn_profile_select": (_i, [C.c_char_p]),
     "tmpnn_gemm_probe": (_i, [_i, _p, _p, _p, _i64, _i, _p]),
     "tmpnn_clock_probe": (_i, [_i, _i, _p, _p, _p]),
+    "tmpnn_clock_monitor": (_i, [_i, _p, _p]),
     "tmpnn_launch_probe": (_i, [_i, _i, _i, _i, _p, _i, _p]),
 }
 PRECISIONS = ("f16x2", "bf16x3", "fp32")

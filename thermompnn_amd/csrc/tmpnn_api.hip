@@ -134,6 +134,13 @@ const char *tm_find_wimg(const float *base) {       // wimg[] is sorted by base 
     }
     return lo < w->n_wimg && w->wimg[lo].base == base ? w->wimg[lo].img : nullptr;
 }
+const char *tm_find_wimgp(const float *base) {
+    const tmpnn_weights *w = g_cur_w;
+    if (!w || !base) return nullptr;
+    for (int i = 0; i < w->n_wimgp; ++i)
+        if (w->wimgp[i].base == base) return w->wimgp[i].img;
+    return nullptr;
+}
 int tm_matmul_mode() {
     if (g_mode >= 0) return g_mode;
     const int d = default_mode();
@@ -227,7 +234,7 @@ static const size_t POS_TABLE_FLOATS = 66 * TMPNN_HID, SEQ_TABLE_FLOATS = TMPNN_
                     CONV_CENTER_FLOATS = 384 * 384;
 static size_t packed_bytes_for(int mode) {    // the f16 fragment images exist for f16x2 handles only (nothing else reads them)
     return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float) +
-           (mode == TM_MM_F16X2 ? (size_t)TM_N_WIMG * TM_WIMG_BYTES : 0);
+           (mode == TM_MM_F16X2 ? (size_t)(TM_N_WIMG + TM_N_WIMGP) * TM_WIMG_BYTES : 0);
 }
 extern "C" size_t tmpnn_weights_packed_bytes(void) { return packed_bytes_for(TM_MM_F16X2); }   // upper bound over the precisions
 extern "C" size_t tmpnn_weights_packed_bytes_p(const char *precision) {
@@ -348,6 +355,16 @@ extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const 
             add(d.W1 + 128, 512); add(d.W2, 128);
         }
         std::sort(w->wimg, w->wimg + w->n_wimg, [](const WImg &x, const WImg &y) { return x.base < y.base; });   // tm_find_wimg searches it
+        auto addp = [&](const float *base, int ld) {     // K-permuted images (msg8_wave_kernel)
+            if (rc != TMPNN_OK || w->n_wimgp >= TM_N_WIMGP) return;
+            w->wimgp[w->n_wimgp++] = WImg{base, img};
+            rc = launch_prep_wimg(base, ld, img, (hipStream_t)stream, 128, 128, 0, true);
+            img += TM_WIMG_BYTES;
+        };
+        for (int l = 0; l < 3; ++l) {
+            addp(w->enc[l].W1 + 128, 384); addp(w->enc[l].W2, 128);
+            addp(w->dec[l].W1 + 128, 512); addp(w->dec[l].W2, 128);
+        }
     }
     if (rc != TMPNN_OK) { delete w; return rc; }
     *out = w;
@@ -519,6 +536,13 @@ extern "C" int tmpnn_gemm_probe(int mode, const float *X, const float *W, float 
 extern "C" int tmpnn_clock_probe(int blocks, int iters, uint64_t *out, float *sink, tmpnn_stream_t stream) {
     REQUIRE(blocks > 0 && iters > 0 && out && sink, "clock_probe: bad argument");
     return launch_clock_probe(blocks, iters, (unsigned long long *)out, sink, (hipStream_t)stream);
+}
+
+// measurement hook: the clock the chip keeps under whatever runs beside it (one sleeping wavefront on `stream`): out[0] = shader cycles,
+// out[1] = 100 MHz ticks over iters x s_sleep 127 (~8 100 cycles each)
+extern "C" int tmpnn_clock_monitor(int iters, uint64_t *out, tmpnn_stream_t stream) {
+    REQUIRE(iters > 0 && out, "clock_monitor: bad argument");
+    return launch_clock_monitor(iters, (unsigned long long *)out, (hipStream_t)stream);
 }
 
 // measurement hook: n dependent launches of a kernel that does (almost) nothing — the box's own price of a kernel boundary, to set

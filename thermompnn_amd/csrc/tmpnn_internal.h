@@ -20,6 +20,8 @@ struct DecW {
 // instead of 16-row gathers of fp32 that are split on the fly (tmpnn_split.hip: node_update8_split_kernel).
 #define TM_WIMG_BYTES 65536
 #define TM_N_WIMG 110          // enc: W3 + 4 W_in + 4 W_out + W1a W1c W11a W11c + W1e W2 W11e W12 W13 (18) x 3; dec: W3 + 4 + 4 + W1a W1d + W1e W2 (13) x 3; head: 9 blocks of the centre tap + 3 of both_out.1; featurizer: 4 blocks of W_edge[:, 16:416] + W_e
+#define TM_N_WIMGP 12          // the message kernels' W1e and W2 again (3 encoder + 3 decoder layers) with the K axis permuted inside every 32-deep step
+                               // (msg8_wave_kernel, tmpnn_msg.hip): element e of lane group q <-> k = 32 c + 16 (e >> 2) + 4 q + (e & 3)
 struct WImg { const float *base; const char *img; };      // base = address of the block's element [0][0] in the raw tensor
 
 struct tmpnn_weights {
@@ -27,6 +29,8 @@ struct tmpnn_weights {
     int mode;              // TM_MM_*: matrix-core path of this handle's per-edge GEMMs
     WImg wimg[TM_N_WIMG];  // derived fragment images (in the caller's packed buffer), looked up by block base address
     int n_wimg;
+    WImg wimgp[TM_N_WIMGP]; // K-permuted images (few: linear search)
+    int n_wimgp;
     const float *t[TMPNN_N_TENSORS];
     // features
     const float *pos_w, *pos_b, *edge_w, *norm_edges_w, *norm_edges_b, *We_w, *We_b, *Ws_w;
@@ -114,6 +118,7 @@ int launch_range_check(const float *x, int64_t n, int32_t *status, hipStream_t s
 int launch_prep_tables(tmpnn_weights *w, hipStream_t st);
 
 int launch_clock_probe(int blocks, int iters, unsigned long long *out, float *sink, hipStream_t st);
+int launch_clock_monitor(int iters, unsigned long long *out, hipStream_t st);
 // tmpnn_split.hip (mode = TM_MM_F16X2 | TM_MM_BF16X3)
 int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
@@ -151,8 +156,9 @@ struct TmModeScope {                  // entry points that take a handle open on
     explicit TmModeScope(const tmpnn_weights *w);
     ~TmModeScope();
 };
-int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st, int n_rows = 128, int k_valid = 128, int k_wrap = 0);       // tmpnn_split.hip
+int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st, int n_rows = 128, int k_valid = 128, int k_wrap = 0, bool perm = false);       // tmpnn_split.hip
 const char *tm_find_wimg(const float *base);                                   // nullptr if no image (or no handle in scope)
+const char *tm_find_wimgp(const float *base);                                  // ... the K-permuted image of a full 128 x 128 block
 // Non-finite tests under -fno-honor-nans. The kernels are built with relaxed NaN semantics, so hipcc may fold a NaN test
 // on the RESULT of floating-point arithmetic (measured: both the sum test and the exponent-bit test on a computed value
 // were compiled away; only the inf half survives). Tests are therefore made on raw bits LOADED FROM MEMORY, before any

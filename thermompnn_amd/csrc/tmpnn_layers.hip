@@ -598,3 +598,18 @@ int launch_clock_probe(int blocks, int iters, unsigned long long *out, float *si
     clock_probe_kernel<<<blocks, TM_THREADS, 0, st>>>(iters, out, sink);
     return tm_check_launch("clock_probe");
 }
+
+// One sleeping wavefront (no LDS, a handful of registers: it fits beside any kernel of the library) that reads the shader cycle counter
+// and the 100 MHz reference before and after `iters` x s_sleep 127: launched on a side stream while the forward runs on another, it
+// reports the clock the chip actually keeps UNDER THAT LOAD (round 5: 2.03 GHz inside the f16x2 message kernels against 2.38 GHz
+// with their MFMAs removed — the pipeline runs power-limited, docs/NOTEBOOK.md 9.10).
+__global__ void clock_monitor_kernel(int iters, unsigned long long *out) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), t0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) __builtin_amdgcn_s_sleep(127);
+    const unsigned long long c1 = __builtin_readcyclecounter(), t1 = wall_clock64();
+    if (tm_tid() == 0) { out[0] = c1 - c0; out[1] = t1 - t0; }
+}
+int launch_clock_monitor(int iters, unsigned long long *out, hipStream_t st) {
+    clock_monitor_kernel<<<1, 64, 0, st>>>(iters, out);
+    return tm_check_launch("clock_monitor");
+}

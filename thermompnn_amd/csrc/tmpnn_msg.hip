@@ -1,5 +1,5 @@
-// Message pass of an encoder / decoder layer (protein_mpnn_utils.py:816-823, 859-866), split-precision forms: f16x2 = msg8_rp_kernel,
-// bf16x3 = msg8_split_kernel.
+// Message pass of an encoder / decoder layer (protein_mpnn_utils.py:816-823, 859-866), split-precision forms (f16x2 and bf16x3):
+// msg8_rp_kernel.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -9,137 +9,13 @@
 #include "tmpnn_internal.h"
 
 // ------------------------------------------------------------------------------------------------
-// message kernels, split-precision form (8 wavefronts, 1 workgroup per CU, next tile prefetched through registers).
-// Same arithmetic as msg_kernel (tmpnn_layers.hip): Ssum_i = sum_k ma_ik gelu(W2 gelu(pre_ik) + b2).
+// message kernel, split-precision forms (8 wavefronts, 1 workgroup per CU). Same arithmetic as msg_kernel (tmpnn_layers.hip):
+// Ssum_i = sum_k ma_ik gelu(W2 gelu(pre_ik) + b2).
 // ------------------------------------------------------------------------------------------------
-template <typename SP, bool DEC>
-__global__ __launch_bounds__(512, 2) void msg8_split_kernel(MsgArgsB a) {
-    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
-    __shared__ __attribute__((aligned(16))) char tE[TILEB];
-    __shared__ __attribute__((aligned(16))) char tA[TILEB];
-    __shared__ __attribute__((aligned(16))) float tS[TM_TILE * TM_H];
-    __shared__ __attribute__((aligned(16))) float tStage[TM_TILE * TM_H];   // next residue's fp32 tile, landed by LDS-DMA
-    __shared__ float s_part[3][TM_H];
-    __shared__ int s_idx[2][TM_TILE];
-    __shared__ float s_ma[2][TM_TILE];
-    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-
-    WFragS<SP> w1[1][4], w2[1][4];
-    load_wfrag_split<SP, 4>(a.W1e, a.ld1, 16 * wv, 0, TM_H, w1[0], lane);
-    load_wfrag_split<SP, 4>(a.W2, TM_H, 16 * wv, 0, TM_H, w2[0], lane);
-    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
-    const f4 bias2 = ld4(a.b2 + ncol);
-
-    auto stage_async = [&](const float *src) {        // linear LDS-DMA of one fp32 tile: 24 x 1 KB, three per wavefront
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int blk = 3 * wv + k;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + blk * 256 + lane * 4),
-                                             (__attribute__((address_space(3))) void *)(tStage + blk * 256), 16, 0, 0);
-        }
-    };
-    auto split_stage = [&]() {
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int idx = it * 512 + tid;
-            store_split<SP>(tE, idx >> 5, idx & 31, ld4(tStage + idx * 4));
-        }
-    };
-    auto stage_idx = [&](int ii, int buf) {           // neighbour list + attention mask of residue ii -> LDS
-        if (tid < TM_TILE) {
-            const int j = a.E_idx[(size_t)ii * TM_KS + tid];
-            s_idx[buf][tid] = j;
-            s_ma[buf][tid] = j < 0 ? 0.f : (DEC ? 1.f : a.mask[ii] * a.mask[j]);
-        }
-    };
-    f4 g0, gj[3];                                      // node terms of the tile about to be processed
-    auto gather = [&](int ii, int buf) {
-        g0 = ld4(a.P + (size_t)ii * 256 + ncol);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const int j0 = s_idx[buf][16 * rb + m];
-            const int j = j0 < 0 ? ii : j0;
-            gj[rb] = ld4(a.P + (size_t)j * 256 + 128 + ncol);
-        }
-    };
-
-    const TileRange tr = xcd_tile_range(a.T);
-    int i = tr.begin;
-    int cur = 0;
-    if (i < tr.end) {
-        stage_idx(i, 0);
-        stage_async(a.hE + (size_t)i * TM_KS * TM_H);
-        __syncthreads();
-        split_stage();
-        gather(i, 0);
-        __syncthreads();
-    }
-    for (; i < tr.end; i += tr.step) {
-        const int inext = i + tr.step;
-        const bool has_next = inext < tr.end;
-        const float mi = a.mask[i];
-        if (has_next) {
-            stage_async(a.hE + (size_t)inext * TM_KS * TM_H);
-            stage_idx(inext, cur ^ 1);
-        }
-        f4 acc[3][1];
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
-        mma_tile_split<SP, 4, 1>(tE, w1, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            f4 v = acc[rb][0];
-            if (DEC) v = g0 + mi * v;
-            store_split<SP>(tA, 16 * rb + m, c4, gelu4(v));
-        }
-        __syncthreads();                                         // tE consumed; tA, tStage, s_idx/s_ma[next] complete
-
-        if (has_next) {
-            split_stage();
-            gather(inext, cur ^ 1);
-        }
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = bias2;
-        mma_tile_split<SP, 4, 1>(tA, w2, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const float ma = s_ma[cur][16 * rb + m];
-            f4 v = gelu4(acc[rb][0]) * ma;
-            if (ma == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
-            st4(tS + chunk_off(16 * rb + m, c4), v);
-        }
-        if (wv == 2) {                                           // neighbour count of this tile (read before s_ma[cur] is recycled):
-            float c = lane < TM_TILE ? s_ma[cur][lane] : 0.f;    // one wavefront-wide DPP sum (a serial 48-term loop in one lane
-#define TM_DPP_ADD(ctrl, row_mask, bc)                                                                  \
-            c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), ctrl, row_mask, 0xf, bc));
-            TM_DPP_ADD(0x111, 0xf, true)                         // held the other seven wavefronts at the barrier for ~350 cycles)
-            TM_DPP_ADD(0x112, 0xf, true)
-            TM_DPP_ADD(0x114, 0xf, true)
-            TM_DPP_ADD(0x118, 0xf, true)                         // lane 15 of every row: the row's sum
-            TM_DPP_ADD(0x142, 0xa, false)                        // row_bcast:15 into rows 1 and 3
-            TM_DPP_ADD(0x143, 0xc, false)                        // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-#undef TM_DPP_ADD
-            if (lane == 63) a.cnt[i] = c;
-        }
-        __syncthreads();
-        {   // per-node aggregation: column sums over 4 row groups of 12, combined in a fixed order
-            const int n = tid & 127, grp = tid >> 7;
-            float s = 0.f;
-#pragma unroll
-            for (int r = 12 * grp; r < 12 * grp + 12; ++r) s += tS[chunk_off(r, n >> 2) + (n & 3)];
-            if (grp) s_part[grp - 1][n] = s;
-            __syncthreads();
-            if (!grp) a.Ssum[(size_t)i * TM_H + n] = ((s + s_part[0][n]) + s_part[1][n]) + s_part[2][n];
-        }
-        cur ^= 1;
-        // no barrier here: the next iteration writes tA only after its own GEMM1 (behind which every wavefront has
-        // passed the barrier above), tS / s_part only after two more barriers, and s_idx/s_ma[cur^1] = the buffers
-        // of the iteration before this one.
-    }
-}
-
-// Register-prefetch form of the message kernel (f16x2): the next residue's fp32 tile is loaded in the accumulator
-// layout at the top of the iteration and split into the e planes once GEMM 1 has consumed the current ones.
+// Register-prefetch form: the next residue's fp32 tile is loaded in row layout at the top of the iteration and split into the
+// e planes once GEMM 1 has consumed the current ones. Both split precisions run it: f16x2 (168-172 VGPRs) and bf16x3 (three planes,
+// 48 weight VGPRs per matrix: 228-230 VGPRs, no scratch; until round 5 bf16x3 staged the tile through LDS-DMA + an fp32 LDS tile
+// and summed over K through LDS: 0.32 ms per launch of the bench batch against 0.284 ms in this form).
 // OFF32: the node-projection table is smaller than 4 GB (T < 2^22 rows), so a gathered row is addressed as the uniform table
 // pointer + a 32-bit per-lane byte offset (one VALU op per gather instead of a 64-bit shift + add chain); every other global access
 // of the loop is a wave-uniform base + a per-thread offset computed once, whatever T is.
@@ -307,6 +183,238 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One wavefront per residue, no workgroup barrier in the loop (round 5; f16x2, launches with >= TM_MSG_WAVE_MIN residues per wavefront).
+// The 8-wavefront form above splits the 128 output columns of a GEMM over the wavefronts of a workgroup, so the next GEMM (whose K axis
+// IS those columns) starts behind a barrier, every epilogue ends in one, and the SIMD's two wavefronts run matrix and vector phases in
+// lock-step: pipe times ADD (docs/NOTEBOOK.md 9.2-9.5). Here a wavefront owns 16 edge rows for the whole chain
+//     e (global) -> B operand -> GEMM 1 -> GELU -> B operand -> GEMM 2 -> GELU -> masked sum over the rows
+// and the activations never leave its registers: v_mfma_f32_16x16x32_f16 with A = weights, B = activations leaves lane (n, q) holding
+// output columns 16 cb + 4 q + {0..3} of edge row n — and the 8 K values lane (n, q) feeds into step c of the NEXT GEMM may be ANY 8, as
+// long as the weight fragment of that step uses the same assignment: the K-permuted fragment images (prep_wimg_kernel, perm) pair
+// accumulator blocks 2 c and 2 c + 1. The same order makes the loads of e 64 contiguous bytes per four lanes. Weights: both matrices'
+// images (2 x 64 KB) in LDS, read as conflict-free 1 KB fragments; the LDS read volume per residue equals that of the A-fragment
+// reads of the 8-wavefront form. The wavefronts of a workgroup share nothing but those images, drift apart, and one's matrix phase
+// runs beside the other's vector phase.
+// ------------------------------------------------------------------------------------------------
+#define TM_MSG_WAVE_MIN 2
+#ifndef TM_MSG_WAVE_ILV
+#define TM_MSG_WAVE_ILV 2       // accumulators whose three partial products are interleaved (see mma_wave_lds)
+#endif
+
+// acc[cb] += W[16 cb .. 16 cb + 16, :] . x over K = 128: 32 (step, block) units of 3 MFMAs; wl = the image in LDS + 16 * lane.
+// The three partial products of a unit go into ONE accumulator: back to back they run at the matrix core's LATENCY (a dependent
+// v_mfma_f32_16x16x32_f16 issues every ~32 cycles, an independent one every 16). In the 8-wavefront kernels the SIMD's other wavefront
+// is always in the same GEMM and fills the gaps; here it usually is not (first build: 38.7 cycles per MFMA), so ILV units on
+// different accumulators are interleaved term by term. Fragments: double-buffered by group of ILV units.
+__device__ __forceinline__ void mma_wave_lds(const char *wl, const u4 (&x)[4][2], f4 (&acc)[8]) {
+    constexpr int NS = 32, ILV = TM_MSG_WAVE_ILV, NG = NS / ILV;
+    u4 w[2][ILV][2];
+#if TM_ABL_NOMFMA
+    return;
+#endif
+    auto request = [&](int g, int half) {
+#if defined(TM_ABL_WAVE_NOLDS)
+        if (g > 1) return;                        // timing ablation (debug builds): the first two groups' fragments, reused
+#endif
+#pragma unroll
+        for (int k = 0; k < ILV; ++k) {
+            const int s = g * ILV + k;
+            w[half][k][0] = *reinterpret_cast<const u4 *>(wl + (s & 7) * 8192 + (s >> 3) * 2048);
+            w[half][k][1] = *reinterpret_cast<const u4 *>(wl + (s & 7) * 8192 + (s >> 3) * 2048 + 1024);
+        }
+    };
+    request(0, 0);
+#define TM_HF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int h = g & 1;
+        if (g + 1 < NG) request(g + 1, h ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const u4 (&xs)[2] = x[(g * ILV) >> 3];
+#pragma unroll
+        for (int k = 0; k < ILV; ++k) acc[(g * ILV + k) & 7] = TM_HF(w[h][k][1], xs[0], acc[(g * ILV + k) & 7]);      // l h
+#pragma unroll
+        for (int k = 0; k < ILV; ++k) acc[(g * ILV + k) & 7] = TM_HF(w[h][k][0], xs[1], acc[(g * ILV + k) & 7]);      // h l
+#pragma unroll
+        for (int k = 0; k < ILV; ++k) acc[(g * ILV + k) & 7] = TM_HF(w[h][k][0], xs[0], acc[(g * ILV + k) & 7]);      // h h
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef TM_HF
+}
+// accumulator blocks 2 c, 2 c + 1 (fp32) -> the B operand of step c
+__device__ __forceinline__ void split_pair(const f4 a, const f4 b, u4 (&x)[2]) {
+    unsigned p0[2], p1[2], p2[2], p3[2];
+    SplitH2::split2(f2{a.x, a.y}, p0);
+    SplitH2::split2(f2{a.z, a.w}, p1);
+    SplitH2::split2(f2{b.x, b.y}, p2);
+    SplitH2::split2(f2{b.z, b.w}, p3);
+    x[0] = u4{p0[0], p1[0], p2[0], p3[0]};
+    x[1] = u4{p0[1], p1[1], p2[1], p3[1]};
+}
+
+template <bool DEC, bool OFF32, bool PROF = false>
+__global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned long long *prof = nullptr) {
+    unsigned long long t_last = 0;
+    auto mark = [&](int k) {           // TMPNN_MSG_PROF=1 (debug library): phase timing of one wavefront of workgroup 0
+        if (PROF && tm_bid() == 0 && (tm_tid() & ~63) == (TM_PROF_TID & ~63) && (tm_tid() & 63) == 0) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            if (k >= 0) prof[k] += t - t_last;
+            t_last = t;
+        }
+    };
+    __shared__ __attribute__((aligned(16))) char sW[2 * TM_WIMG_BYTES];
+    __shared__ __attribute__((aligned(16))) float s_g0[8][TM_H];    // the residue's own projection row, per wavefront
+    __shared__ __attribute__((aligned(16))) float s_b2[TM_H];
+    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
+    for (int o = tid * 16; o < TM_WIMG_BYTES; o += 512 * 16) {
+        *reinterpret_cast<u4 *>(sW + o) = *reinterpret_cast<const u4 *>(a.imgp1 + o);
+        *reinterpret_cast<u4 *>(sW + TM_WIMG_BYTES + o) = *reinterpret_cast<const u4 *>(a.imgp2 + o);
+    }
+    if (tid < TM_H / 4) st4(&s_b2[4 * tid], ld4(a.b2 + 4 * tid));
+    __syncthreads();                                            // the only barrier of the kernel
+    const char *wl1 = sW + 16 * lane, *wl2 = sW + TM_WIMG_BYTES + 16 * lane;
+    float *g0s = s_g0[wv];
+
+    const TileRange tr = xcd_tile_range(a.T);
+    const int istep = 8 * tr.step;
+    int i = tr.begin + wv * tr.step;
+    if (i >= tr.end) return;
+    const unsigned uq = 4u * (unsigned)q;
+    const unsigned eoff = (unsigned)(n * TM_H) + uq;           // this lane's offset inside a 16-row block of e
+
+    auto idx_of = [&](int ii, int bb) { return (a.E_idx + ((size_t)__builtin_amdgcn_readfirstlane(ii) * TM_KS + 16 * __builtin_amdgcn_readfirstlane(bb)))[(unsigned)n]; };
+    f4 e_n[8], g_n[8];
+    float mk_n = 1.f;
+    auto issue_block = [&](int ii, int bb, int j) {            // operands of block (ii, bb) whose list entry j has arrived
+        const int jj = j < 0 ? ii : j;
+        if constexpr (OFF32) {
+            const unsigned off = (unsigned)jj * 256u + (128u + uq);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) g_n[cb] = ld4(a.P + (off + 16u * cb));
+        } else {
+            const float *pj = a.P + (size_t)jj * 256 + 128 + uq;
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) g_n[cb] = ld4(pj + 16 * cb);
+        }
+        if (!DEC) mk_n = a.mask[(unsigned)jj];
+        const float *src = a.hE + ((size_t)__builtin_amdgcn_readfirstlane(ii) * TM_KS + 16 * __builtin_amdgcn_readfirstlane(bb)) * TM_H;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) e_n[c] = ld4(src + (eoff + 16u * c));     // c = 2 step + half: columns 32 step + 16 half + 4 q
+    };
+    f4 g0_n = f4{0.f, 0.f, 0.f, 0.f};
+    float mi_n = 0.f;
+    auto issue_self = [&](int ii) {
+        if (lane < 32) g0_n = ld4(a.P + (size_t)__builtin_amdgcn_readfirstlane(ii) * 256 + 4 * lane);
+        mi_n = (a.mask + __builtin_amdgcn_readfirstlane(ii))[0];
+    };
+
+    int j_cur = idx_of(i, 0), j_nxt = idx_of(i, 1);
+    issue_block(i, 0, j_cur);
+    issue_self(i);
+    f4 sum[8];
+    float mi = 0.f, cnt = 0.f;
+    mark(-1);
+    unsigned long long c_begin = 0, w_begin = 0;
+    if (PROF) { c_begin = __builtin_readcyclecounter(); w_begin = wall_clock64(); }
+    for (;;) {                                                  // residues of this wavefront
+        if (lane < 32) st4(g0s + 4 * lane, g0_n);
+        mi = mi_n;
+        cnt = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) sum[cb] = f4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // g0s is read back by this wavefront only (LDS is in order per wavefront)
+        __builtin_amdgcn_wave_barrier();
+        const bool more = i + istep < tr.end;                   // this wavefront has another residue
+#pragma unroll 1
+        for (int b = 0; b < 3; ++b) {                           // its three 16-row blocks: the loop tools/isa_counts.py counts
+            // ---- the block's operands (requested one block ago)
+            u4 x[4][2];
+            f4 acc[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) split_pair(e_n[2 * c], e_n[2 * c + 1], x[c]);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) acc[cb] = DEC ? g_n[cb] : g_n[cb] + ld4(g0s + 16 * cb + uq);
+            // consumed HERE, in front of the requests that refill e_n / g_n: left free, hipcc sinks these into the block of their first
+            // use (behind the requests), the old and the new operands are live together and every one of them is copied at the back edge
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { asm volatile("" : "+v"(x[c][0]), "+v"(x[c][1])); }
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) touch(acc[cb]);
+            mark(0);
+            const float ma = j_cur < 0 ? 0.f : (DEC ? 1.f : mi * mk_n);
+            // ---- requests: the next block's operands, the list entry of the block after it. UNCONDITIONAL (the last block of a
+            // wavefront asks for its own operands again): a request under `if (more)` makes every operand register a phi that hipcc
+            // copies around the loop — 64 v_mov_b64 per block in the first build of this kernel
+            const bool last_b = b == 2;
+            const bool has1 = !last_b || more;
+            const int i1 = has1 ? (last_b ? i + istep : i) : i, b1 = has1 ? (last_b ? 0 : b + 1) : b;
+            issue_block(i1, b1, has1 ? j_nxt : j_cur);
+            if (last_b) issue_self(i1);
+            {
+                const bool last_b1 = b1 == 2;
+                const int i2 = last_b1 ? i1 + istep : i1, b2 = last_b1 ? 0 : b1 + 1;
+                const bool has2 = has1 && i2 < tr.end;
+                j_cur = j_nxt;
+                j_nxt = idx_of(has2 ? i2 : i1, has2 ? b2 : b1);
+            }
+            // ---- the chain
+            mark(1);
+            mma_wave_lds(wl1, x, acc);
+            mark(2);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f4 v0 = acc[2 * c], v1 = acc[2 * c + 1];
+                if (DEC) {
+                    v0 = ld4(g0s + 32 * c + uq) + mi * v0;
+                    v1 = ld4(g0s + 32 * c + 16 + uq) + mi * v1;
+                }
+                split_pair(gelu4(v0), gelu4(v1), x[c]);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) acc[cb] = ld4(s_b2 + 16 * cb + uq);
+            mark(3);
+            mma_wave_lds(wl2, x, acc);
+            mark(4);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const f4 g = gelu4(acc[cb]);
+                sum[cb] = f4{__builtin_fmaf(g.x, ma, sum[cb].x), __builtin_fmaf(g.y, ma, sum[cb].y), __builtin_fmaf(g.z, ma, sum[cb].z), __builtin_fmaf(g.w, ma, sum[cb].w)};
+            }
+            cnt += ma;
+            mark(5);
+        }
+        // ---- sums over the 16 rows of a lane group (DPP row_shr scan: lane n = 15 ends up with the total)
+#define TM_ROW_SCAN(x)                                                                                  \
+        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));  \
+        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xf, 0xf, true));  \
+        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, true));  \
+        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xf, 0xf, true));
+        // the totals (lane n = 15 of every lane group: 8 x 4 columns) meet in this wavefront's LDS row — the residue's own projection,
+        // consumed by now — and leave as ONE 512-byte store
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+            f4 t = sum[cb];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { float v = t[k]; TM_ROW_SCAN(v) t[k] = v; }
+            if (n == 15) st4(g0s + 16 * cb + uq, t);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) st4(a.Ssum + (size_t)__builtin_amdgcn_readfirstlane(i) * TM_H + 4 * lane, ld4(g0s + 4 * lane));
+        TM_ROW_SCAN(cnt)
+#undef TM_ROW_SCAN
+        if (lane == 15) a.cnt[i] = cnt;
+        mark(6);
+        if (!more) break;
+        i += istep;
+    }
+    if (PROF && tm_bid() == 0 && tm_tid() == (TM_PROF_TID & ~63)) {       // shader cycles and 100 MHz ticks of the loop: the clock under THIS load
+        prof[8] = __builtin_readcyclecounter() - c_begin;
+        prof[9] = wall_clock64() - w_begin;
+    }
+}
+
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
                      const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt,
                      hipStream_t st) {
@@ -314,9 +422,37 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
     MsgArgsB a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T, h2 ? tm_find_wimg(W1e) : nullptr, h2 ? tm_find_wimg(W2) : nullptr};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
-    if (mode == TM_MM_BF16X3) {                      // staged through LDS (the exact three-plane tiles leave no VGPRs for a register prefetch)
-        if (dec) msg8_split_kernel<SplitBF3, true><<<grid, 512, 0, st>>>(a);
-        else msg8_split_kernel<SplitBF3, false><<<grid, 512, 0, st>>>(a);
+    const bool off32 = T < ((int64_t)1 << 22);       // projection table < 4 GB: 32-bit gather offsets
+    a.imgp1 = h2 ? tm_find_wimgp(W1e) : nullptr;
+    a.imgp2 = h2 ? tm_find_wimgp(W2) : nullptr;
+    if (h2 && a.imgp1 && a.imgp2 && T >= (int64_t)TM_MSG_WAVE_MIN * 8 * cap) {       // one wavefront per residue
+#ifdef TMPNN_DEBUG_BUILD
+        static const bool wprof = TM_DBG_FLAG("TMPNN_MSG_PROF", false);
+        if (wprof && dec) {                          // debug build: phase timing of one wavefront of workgroup 0 (synchronises!)
+            static unsigned long long *d_prof = nullptr;
+            if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
+            (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+            msg8_wave_kernel<true, false, true><<<(int)cap, 512, 0, st>>>(a, d_prof);
+            unsigned long long h[16];
+            (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "dec_msg wave phases (cycles, one wavefront of wg 0, all its blocks): operands %llu requests %llu gemm1 %llu gelu+split %llu gemm2 %llu gelu+mask %llu ksum+store %llu; loop %llu cycles in %llu ticks of 100 MHz = %.3f GHz\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[9] ? h[8] / (h[9] * 10.0) : 0.0);
+            return tm_check_launch("dec_msg_wave");
+        }
+#endif
+        if (off32) {
+            if (dec) msg8_wave_kernel<true, true><<<(int)cap, 512, 0, st>>>(a);
+            else msg8_wave_kernel<false, true><<<(int)cap, 512, 0, st>>>(a);
+        } else if (dec) msg8_wave_kernel<true, false><<<(int)cap, 512, 0, st>>>(a);
+        else msg8_wave_kernel<false, false><<<(int)cap, 512, 0, st>>>(a);
+        return tm_check_launch(dec ? "dec_msg_wave" : "enc_msg_wave");
+    }
+    if (mode == TM_MM_BF16X3) {
+        if (off32) {
+            if (dec) msg8_rp_kernel<SplitBF3, true, false, true><<<grid, 512, 0, st>>>(a);
+            else msg8_rp_kernel<SplitBF3, false, false, true><<<grid, 512, 0, st>>>(a);
+        } else if (dec) msg8_rp_kernel<SplitBF3, true><<<grid, 512, 0, st>>>(a);
+        else msg8_rp_kernel<SplitBF3, false><<<grid, 512, 0, st>>>(a);
     } else {
 #ifdef TMPNN_DEBUG_BUILD
         static const bool prof = TM_DBG_FLAG("TMPNN_MSG_PROF", false);
@@ -334,7 +470,7 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
             fprintf(stderr, "dec_msg phases (cycles, wg 0): fetch+gemm1 %llu gelu+split %llu bar %llu split_tile+gather %llu gemm2 %llu gelu+mask %llu bar %llu ksum+store %llu\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
 #endif
-        } else if (T < ((int64_t)1 << 22)) {           // projection table < 4 GB: 32-bit gather offsets
+        } else if (off32) {
             if (dec) msg8_rp_kernel<SplitH2, true, false, true><<<grid, 512, 0, st>>>(a);
             else msg8_rp_kernel<SplitH2, false, false, true><<<grid, 512, 0, st>>>(a);
         } else if (dec) msg8_rp_kernel<SplitH2, true><<<grid, 512, 0, st>>>(a);

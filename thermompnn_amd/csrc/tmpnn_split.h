@@ -410,6 +410,7 @@ struct MsgArgsB {
     float *Ssum, *cnt;
     int T;
     const char *img1, *img2;                // fragment images of W1e / W2 (f16x2 only) or null
+    const char *imgp1, *imgp2;              // ... their K-permuted forms (msg8_wave_kernel)
 };
 
 template <int I, int N, typename F>

@@ -80,18 +80,20 @@ int launch_gemm_probe(int mode, const float *X, const float *W, float *Y, int64_
 }
 
 // fragment image of one 128 x 128 block (see WImg in tmpnn_internal.h): [wv 8][c 4][plane 2][lane 64] x 16 B
-__global__ void prep_wimg_kernel(const float *__restrict__ W, int ld, int n_rows, int k_valid, int k_wrap, char *__restrict__ dst) {
+// perm (full blocks only): the 8 values of lane group q in step c are k = 32 c + 4 q + {0..3} and 32 c + 16 + 4 q + {0..3} — the K order in
+// which a wavefront that keeps its activations in the accumulator layout holds them (msg8_wave_kernel)
+__global__ void prep_wimg_kernel(const float *__restrict__ W, int ld, int n_rows, int k_valid, int k_wrap, char *__restrict__ dst, bool perm) {
     const int idx = tm_bid() * tm_bdim() + tm_tid();      // (wv, c, lane)
     if (idx >= 8 * 4 * 64) return;
     const int lane = idx & 63, c = (idx >> 6) & 3, wv = idx >> 8, m = lane & 15, q = lane >> 4;
-    const float *src = W + (size_t)(16 * wv + m) * ld + 32 * c + 8 * q;
+    const float *src = W + (size_t)(16 * wv + m) * ld + 32 * c + (perm ? 4 : 8) * q;
     // blocks with fewer than 128 rows / fewer than 128 columns (k_valid, a multiple of 8): zero fragments beyond, nothing read —
     // except the k_wrap columns after k_valid, which come from the same row one `ld` back (load_wfrag_split)
     const int k = 32 * c + 8 * q;
     const bool ok = 16 * wv + m < n_rows && k < k_valid + k_wrap;
     if (k >= k_valid) src -= ld;
     const f4 z = f4{0.f, 0.f, 0.f, 0.f};
-    const f4 v0 = ok ? ld4(src) : z, v1 = ok ? ld4(src + 4) : z;
+    const f4 v0 = ok ? ld4(src) : z, v1 = ok ? ld4(src + (perm ? 16 : 4)) : z;
     unsigned w4[4][2];
     SplitH2::split2(f2{v0.x, v0.y}, w4[0]);
     SplitH2::split2(f2{v0.z, v0.w}, w4[1]);
@@ -101,7 +103,7 @@ __global__ void prep_wimg_kernel(const float *__restrict__ W, int ld, int n_rows
     for (int p = 0; p < 2; ++p)
         *reinterpret_cast<u4 *>(dst + (size_t)wv * 8192 + c * 2048 + p * 1024 + lane * 16) = u4{w4[0][p], w4[1][p], w4[2][p], w4[3][p]};
 }
-int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st, int n_rows, int k_valid, int k_wrap) {
-    prep_wimg_kernel<<<8, 256, 0, st>>>(W, ld, n_rows, k_valid, k_wrap, dst);
+int launch_prep_wimg(const float *W, int ld, char *dst, hipStream_t st, int n_rows, int k_valid, int k_wrap, bool perm) {
+    prep_wimg_kernel<<<8, 256, 0, st>>>(W, ld, n_rows, k_valid, k_wrap, dst, perm);
     return tm_check_launch("prep_wimg");
 }
