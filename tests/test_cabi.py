@@ -98,7 +98,7 @@ def test_shipped_library_has_no_environment_switches():
     build.build_debug_library()
     names = [b"TMPNN_KNN_REG", b"TMPNN_KNN_SEL", b"TMPNN_FEAT_IMG", b"TMPNN_FEAT_WAVES", b"TMPNN_FEAT_SPLIT", b"TMPNN_FEAT_PROF",
              b"TMPNN_HEAD_SPLIT", b"TMPNN_NODE_IMG", b"TMPNN_NODE_SPLIT", b"TMPNN_NODE_DEEP", b"TMPNN_NODE_PROF", b"TMPNN_EDGE_PROF",
-             b"TMPNN_MSG_PROF"]
+             b"TMPNN_MSG_PROF", b"TMPNN_MSG_WAVE_MIN", b"TMPNN_FUSE_SMALL"]
     shipped, debug = open(_lib.LIB_PATH, "rb").read(), open(_lib.DEBUG_LIB_PATH, "rb").read()
     assert not [n for n in names if n in shipped]
     assert all(n in debug for n in names)

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
             mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tX, fb, acc, lane);
             __builtin_amdgcn_sched_barrier(0);
-            load_wfrag_auto<SP>(b.img1, b.W1e, b.ld1, wv, lane, fb[0]);          // W12 is done with: the message pass's W1
+            load_wfrag_auto<SP, true>(b.imgp1, b.W1e, b.ld1, wv, lane, fb[0]);   // W12 is done with: the message pass's W1 (its K order: perm_c4)
             {
                 f4 g[3];
 #pragma unroll
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
             mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tY, fa, acc, lane);
             __builtin_amdgcn_sched_barrier(0);
-            load_wfrag_auto<SP>(b.img2, b.W2, TM_H, wv, lane, fa[0]);            // W13 is done with: the message pass's W2
+            load_wfrag_auto<SP, true>(b.imgp2, b.W2, TM_H, wv, lane, fa[0]);     // W13 is done with: the message pass's W2
             bias2 = ld4(b.b2 + ncol);
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             if (tid < TM_TILE) s_ma[tid] = s_idx[tid] < 0 ? 0.f : (DEC ? 1.f : mi * nma);
             const int prow = 6 * wv + (lane >> 5), pc = lane & 31;              // the row layout the tile was just produced in
 #pragma unroll
-            for (int it = 0; it < 3; ++it) store_split<SP>(tE, prow + 2 * it, pc, yrow[it]);
+            for (int it = 0; it < 3; ++it) store_split<SP>(tE, prow + 2 * it, perm_c4(pc), yrow[it]);       // the message pass's K order
             __syncthreads();                                                     // e planes + s_ma complete; tO (= tA) consumed
             f4 acc[3][1];
 #pragma unroll
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             for (int rb = 0; rb < 3; ++rb) {
                 f4 v = acc[rb][0];
                 if (DEC) v = g0 + mi * v;
-                store_split<SP>(tX, 16 * rb + m, c4, gelu4(v));
+                store_split<SP>(tX, 16 * rb + m, perm_c4(c4), gelu4(v));
             }
             __syncthreads();
 #pragma unroll
@@ -201,7 +201,7 @@ int launch_edge_msg_fused(const EncW &e, const float *P_edge, float *hE, const i
                           hipStream_t st) {
     EdgeArgsB a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P_edge, hE, E_idx, (int)T,
                 tm_find_wimg(e.W11 + 128), tm_find_wimg(e.W12), tm_find_wimg(e.W13)};
-    MsgArgsB b{W1e, ld1, W2, b2, P_msg, hE, E_idx, mask, Ssum, cnt, (int)T, tm_find_wimg(W1e), tm_find_wimg(W2)};
+    MsgArgsB b{W1e, ld1, W2, b2, P_msg, hE, E_idx, mask, Ssum, cnt, (int)T, tm_find_wimg(W1e), tm_find_wimg(W2), tm_find_wimgp(W1e), tm_find_wimgp(W2), 0};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
     tm_prof_begin("edge_msg_fused", st);

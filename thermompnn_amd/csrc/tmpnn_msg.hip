@@ -36,10 +36,12 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     __shared__ float s_ma[2][TM_TILE];
     const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
+    constexpr bool PERM = SP::NP == 2;                          // f16x2: the message pass's K order (perm_c4, tmpnn_split.h)
     WFragS<SP> w1[1][4], w2[1][4];
-    load_wfrag_auto<SP>(a.img1, a.W1e, a.ld1, wv, lane, w1[0]);
-    load_wfrag_auto<SP>(a.img2, a.W2, TM_H, wv, lane, w2[0]);
+    load_wfrag_auto<SP, PERM>(PERM ? a.imgp1 : a.img1, a.W1e, a.ld1, wv, lane, w1[0]);
+    load_wfrag_auto<SP, PERM>(PERM ? a.imgp2 : a.img2, a.W2, TM_H, wv, lane, w2[0]);
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
+    const int c4s = PERM ? perm_c4(c4) : c4;                    // where this thread's column group goes in a plane row
     const f4 bias2 = ld4(a.b2 + ncol);
 
     auto stage_idx = [&](int ii, int buf) {           // neighbour list + attention mask of residue ii -> LDS
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     // row layout: one half-wavefront per 512-byte row, fully coalesced (the message kernels never need the tile in
     // the accumulator layout)
     const int prow = 6 * wv + (lane >> 5), pc = lane & 31;
+    const int pcs = PERM ? perm_c4(pc) : pc;
     const unsigned eoff = (unsigned)(prow * TM_H + 4 * pc);         // this thread's offset inside any e tile
     auto fetch_into = [&](f4 (&dst)[3], int ii) {
         const float *src = a.hE + (size_t)__builtin_amdgcn_readfirstlane(ii) * (TM_KS * TM_H);      // wave-uniform: scalar base + lane offset
@@ -73,10 +76,12 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
     auto fetch_tile = [&](int ii) { fetch_into(e_nxt, ii); };
     auto split_tile = [&]() {
 #pragma unroll
-        for (int it = 0; it < 3; ++it) store_split<SP>(tE, prow + 2 * it, pc, e_nxt[it]);
+        for (int it = 0; it < 3; ++it) store_split<SP>(tE, prow + 2 * it, pcs, e_nxt[it]);
     };
 
-    const TileRange tr = xcd_tile_range(a.T);
+    TileRange tr = xcd_tile_range(a.T);
+    tr.begin += a.i0;                                           // residues [i0, i0 + T) of the packed axis
+    tr.end += a.i0;
     int i = tr.begin;
     int cur = 0;
     if (i < tr.end) {
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         for (int rb = 0; rb < 3; ++rb) {
             f4 v = acc[rb][0];
             if (DEC) v = g0 + mi * v;
-            store_split<SP>(tA, 16 * rb + m, c4, gelu4(v));
+            store_split<SP>(tA, 16 * rb + m, c4s, gelu4(v));
         }
         if (tid < TM_TILE) {
             s_idx[cur ^ 1][tid] = nidx;
@@ -197,6 +202,9 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
 // reads of the 8-wavefront form. The wavefronts of a workgroup share nothing but those images, drift apart, and one's matrix phase
 // runs beside the other's vector phase.
 // ------------------------------------------------------------------------------------------------
+// Work unit = one residue of one wavefront (~25 us), so this form takes whole multiples of 8 residues per workgroup; the launcher hands
+// it floor(T / (8 #CUs)) x 8 #CUs residues and the remainder (< 8 per workgroup) to the 8-wavefront form — which computes the same bits
+// (perm_c4, tmpnn_split.h). TM_MSG_WAVE_MIN: the smallest multiple worth a second launch and a 128 KB LDS fill per workgroup.
 #define TM_MSG_WAVE_MIN 2
 #ifndef TM_MSG_WAVE_ILV
 #define TM_MSG_WAVE_ILV 2       // accumulators whose three partial products are interleaved (see mma_wave_lds)
@@ -419,13 +427,21 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
                      const float *hE, const int32_t *E_idx, const float *mask, int64_t T, float *Ssum, float *cnt,
                      hipStream_t st) {
     const bool h2 = mode == TM_MM_F16X2;
-    MsgArgsB a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T, h2 ? tm_find_wimg(W1e) : nullptr, h2 ? tm_find_wimg(W2) : nullptr};
+    MsgArgsB a{W1e, ld1, W2, b2, P, hE, E_idx, mask, Ssum, cnt, (int)T, h2 ? tm_find_wimg(W1e) : nullptr, h2 ? tm_find_wimg(W2) : nullptr,
+               h2 ? tm_find_wimgp(W1e) : nullptr, h2 ? tm_find_wimgp(W2) : nullptr, 0};
     const int64_t cap = tm_num_cus();
-    const int grid = (int)(T < cap ? T : cap);
     const bool off32 = T < ((int64_t)1 << 22);       // projection table < 4 GB: 32-bit gather offsets
-    a.imgp1 = h2 ? tm_find_wimgp(W1e) : nullptr;
-    a.imgp2 = h2 ? tm_find_wimgp(W2) : nullptr;
-    if (h2 && a.imgp1 && a.imgp2 && T >= (int64_t)TM_MSG_WAVE_MIN * 8 * cap) {       // one wavefront per residue
+    // f16x2, large launches: whole multiples of 8 residues per workgroup go one wavefront per residue, the rest (< 8 per workgroup) to
+    // the 8-wavefront form behind it — same K order, same summation order, same bits (tests: config 3 against single-protein forwards)
+    static const int wave_min = TM_DBG_INT("TMPNN_MSG_WAVE_MIN", TM_MSG_WAVE_MIN);   // (debug library: 0 = from one residue per wavefront)
+    int64_t Tw = 0;
+    if (h2 && a.imgp1 && a.imgp2 && cap % 8 == 0) {
+        const int64_t q = T / (8 * cap);
+        if (q >= (wave_min > 0 ? wave_min : 1)) Tw = q * 8 * cap;
+        else if (wave_min == 0 && T > 0) Tw = T;      // (debug switch: everything, whatever the size)
+    }
+    if (Tw > 0) {
+        a.T = (int)Tw;
 #ifdef TMPNN_DEBUG_BUILD
         static const bool wprof = TM_DBG_FLAG("TMPNN_MSG_PROF", false);
         if (wprof && dec) {                          // debug build: phase timing of one wavefront of workgroup 0 (synchronises!)
@@ -437,16 +453,18 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
             (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
             fprintf(stderr, "dec_msg wave phases (cycles, one wavefront of wg 0, all its blocks): operands %llu requests %llu gemm1 %llu gelu+split %llu gemm2 %llu gelu+mask %llu ksum+store %llu; loop %llu cycles in %llu ticks of 100 MHz = %.3f GHz\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[9] ? h[8] / (h[9] * 10.0) : 0.0);
-            return tm_check_launch("dec_msg_wave");
-        }
+        } else
 #endif
         if (off32) {
             if (dec) msg8_wave_kernel<true, true><<<(int)cap, 512, 0, st>>>(a);
             else msg8_wave_kernel<false, true><<<(int)cap, 512, 0, st>>>(a);
         } else if (dec) msg8_wave_kernel<true, false><<<(int)cap, 512, 0, st>>>(a);
         else msg8_wave_kernel<false, false><<<(int)cap, 512, 0, st>>>(a);
-        return tm_check_launch(dec ? "dec_msg_wave" : "enc_msg_wave");
+        if (Tw == T) return tm_check_launch(dec ? "dec_msg_wave" : "enc_msg_wave");
+        a.i0 = (int)Tw;
+        a.T = (int)(T - Tw);
     }
+    const int grid = (int)(a.T < cap ? a.T : cap);
     if (mode == TM_MM_BF16X3) {
         if (off32) {
             if (dec) msg8_rp_kernel<SplitBF3, true, false, true><<<grid, 512, 0, st>>>(a);
@@ -459,7 +477,7 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
 #else
         constexpr bool prof = false;
 #endif
-        if (prof && dec) {                           // debug build: phase timing of workgroup 0 (synchronises!)
+        if (prof && dec && Tw == 0) {                // debug build: phase timing of workgroup 0 (synchronises!)
 #ifdef TMPNN_DEBUG_BUILD
             static unsigned long long *d_prof = nullptr;
             if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));

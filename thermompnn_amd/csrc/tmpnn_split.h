@@ -162,17 +162,19 @@ __device__ __forceinline__ f4 load_joined(const char *tile, int row, int c4) {
 template <typename SP>
 struct WFragS { u4 p[SP::NP]; };
 
-template <typename SP, int NK32>
+// PERM (full 128-deep weights only): the K order of the message kernels (perm_c4 below): lane group q holds k = 32 c + 4 q + {0..3} and
+// 32 c + 16 + 4 q + {0..3} of step c.
+template <typename SP, int NK32, bool PERM = false>
 __device__ __forceinline__ void load_wfrag_split(const float *__restrict__ W, int ld, int n0, int k0, int k_valid,
                                                  WFragS<SP> (&wf)[NK32], int lane, int k_wrap = 0) {
-    const float *src = W + (size_t)(n0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4);
+    const float *src = W + (size_t)(n0 + (lane & 15)) * ld + k0 + (PERM ? 4 : 8) * (lane >> 4);
 #pragma unroll
     for (int c = 0; c < NK32; ++c) {
         unsigned w[4][SP::NP];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int k = 32 * c + 8 * (lane >> 4) + 4 * half;
-            const f4 v = k < k_valid ? ld4(src + 32 * c + 4 * half) : k < k_valid + k_wrap ? ld4(src + 32 * c + 4 * half - ld) : f4{0.f, 0.f, 0.f, 0.f};
+            const int k = 32 * c + (PERM ? 4 : 8) * (lane >> 4) + (PERM ? 16 : 4) * half;
+            const f4 v = k < k_valid ? ld4(src + 32 * c + (PERM ? 16 : 4) * half) : k < k_valid + k_wrap ? ld4(src + 32 * c + 4 * half - ld) : f4{0.f, 0.f, 0.f, 0.f};
             SP::split2(f2{v.x, v.y}, w[2 * half]);
             SP::split2(f2{v.z, v.w}, w[2 * half + 1]);
         }
@@ -378,7 +380,14 @@ __device__ __forceinline__ void row_stats_finish8d(const float *stat_row, int la
 // ------------------------------------------------------------------------------------------------
 // Weight fragment of wavefront wv from a pre-built image (WImg, tmpnn_internal.h): 8 coalesced 16-byte loads instead of the
 // 16-row fp32 gathers + on-the-fly split of load_wfrag_split. img == nullptr -> the gather path.
-template <typename SP>
+// The message pass's K order (round 5). Its wavefront-per-residue form (msg8_wave_kernel) keeps the activations in the MFMA accumulator
+// layout, so lane group q of 32-deep step c holds k = 32 c + 4 q + {0..3} and 32 c + 16 + 4 q + {0..3}. The products of a step are summed
+// inside the matrix core in slot order: for a protein's numbers not to depend on which form its launch took, EVERY f16x2 form of the
+// message pass uses that order — the 8-wavefront forms write their plane tiles with the column group c4 = 8 c + 4 h + q stored where
+// 8 c + 2 q + h would be (a 16-byte chunk then holds exactly one lane group's 8 values), and all read the K-permuted weight images.
+__device__ __forceinline__ int perm_c4(int c4) { return (c4 & ~7) | ((c4 & 3) << 1) | ((c4 >> 2) & 1); }
+
+template <typename SP, bool PERM = false>
 __device__ __forceinline__ void load_wfrag_auto(const char *img, const float *__restrict__ W, int ld, int wv, int lane,
                                                 WFragS<SP> (&wf)[4]) {
     if (img != nullptr && SP::NP == 2) {
@@ -389,7 +398,7 @@ __device__ __forceinline__ void load_wfrag_auto(const char *img, const float *__
             wf[c].p[1] = *reinterpret_cast<const u4 *>(p + 2048 * c + 1024);
         }
     } else {
-        load_wfrag_split<SP, 4>(W, ld, 16 * wv, 0, TM_H, wf, lane);
+        load_wfrag_split<SP, 4, PERM>(W, ld, 16 * wv, 0, TM_H, wf, lane);
     }
 }
 
@@ -410,7 +419,8 @@ struct MsgArgsB {
     float *Ssum, *cnt;
     int T;
     const char *img1, *img2;                // fragment images of W1e / W2 (f16x2 only) or null
-    const char *imgp1, *imgp2;              // ... their K-permuted forms (msg8_wave_kernel)
+    const char *imgp1, *imgp2;              // ... their K-permuted forms (every f16x2 form of the message pass: perm_c4)
+    int i0;                                 // first residue of this launch (a large launch = wavefront-per-residue part + a remainder)
 };
 
 template <int I, int N, typename F>
