@@ -13,7 +13,8 @@ python - <<PY
 import csv, glob, json, collections, sys
 sys.path.insert(0, "$R")
 from bench import kernel_source_stamp
-LOGICAL = [("enc_edge", "enc_edge"), ("msg8_rp_kernel<SplitH2, false", "enc_msg"), ("msg8_rp_kernel<SplitH2, true", "dec_msg"),
+LOGICAL = [("enc_edge", "enc_edge"), ("msg8_wave_kernel<false", "enc_msg"), ("msg8_wave_kernel<true", "dec_msg"),
+           ("msg8_rp_kernel<SplitH2, false", "enc_msg_remainder"), ("msg8_rp_kernel<SplitH2, true", "dec_msg_remainder"),
            ("featurize", "featurize"), ("gather_rows_kernel", "gather_rows"), ("copyBuffer", "device_copy_calibration"),
            ("node_update", "node_update"), ("knn_kernel", "knn"), ("head8_split", "head"), ("node_proj", "node_proj")]
 T, E = 16384, 16384 * 48

@@ -7,8 +7,8 @@ import collections
 import csv
 import sys
 
-PER_STEP = {"knn_kernel": 1, "featurize": 1, "msg8_rp_kernel<SplitH2, false": 3, "msg8_rp_kernel<SplitH2, true": 3, "enc_edge8": 3,
-            "node_update8": 6, "head8": 1}
+PER_STEP = {"knn_kernel": 1, "featurize": 1, "msg8_wave_kernel<false": 3, "msg8_wave_kernel<true": 3,
+            "msg8_rp_kernel<SplitH2, false": 3, "msg8_rp_kernel<SplitH2, true": 3, "enc_edge8": 3, "node_update8": 6, "head8": 1}
 
 
 def main(path, steps):

@@ -96,7 +96,7 @@ res["config5_L2048"] = {"ms": dt * 1e3, "preds_per_s": 40960 / dt, "kernel_avg_m
                         "note": "one 2048-residue chain = 2048 tiles on 256 CUs: 8 tiles per persistent workgroup, so prologues (weight fragments) "
                                 "and the tail weigh more than in the 64-protein batch; k-NN rows > 512 use the LDS form",
                         # default (f16x2) kernels, from hipcc -Rpass-analysis=kernel-resource-usage
-                        "lds_bytes_per_workgroup": {"knn (4 rows, dynamic)": 4 * (2048 + 33) * 4, "featurize_split": 145600, "msg8_rp": 49920,
-                                                    "enc_edge8_rp": 77568, "node_update8 (64 rows)": 126976, "head8": 98432},
+                        "lds_bytes_per_workgroup": {"knn (4 rows, dynamic)": 4 * (2048 + 33) * 4, "featurize_split": 146368, "msg8_rp": 49920, "msg8_wave (launches of >= 16 residues per CU)": 135680,
+                                                    "enc_edge8_rp": 52992, "node_update8 (64 rows)": 126976, "head8": 98432},
                         "waves_per_simd": {"knn": 8, "featurize_split": 2, "msg8_rp": 2, "enc_edge8_rp": 2, "node_update8": 2, "head8": 2}}
 print(json.dumps(res, indent=1))
