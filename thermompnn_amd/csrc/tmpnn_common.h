@@ -151,9 +151,10 @@ __device__ __forceinline__ f2 pk_horner(f2 q, f2 t, float c) {
 // Timing-only ablations (tools/ablate.sh: ONE ingredient removed, results wrong by construction) exist in debug builds only — the
 // shipped library compiles exactly one form of every kernel: TM_ABL_NOGELU (GELU = identity), TM_ABL_NOSPLIT (high plane only),
 // TM_ABL_NOMFMA (tile GEMMs issue nothing), TM_ABL_NOLN (edge update without LayerNorm statistics), TM_ABL_NOLOAD (per-edge kernels
-// never fetch the next tile), TM_ABL_NOGAUSS (featurizer without Gaussians).
+// never fetch the next tile), TM_ABL_NOGAUSS (featurizer without Gaussians), TM_ABL_WAVE_NOLDS (wavefront-per-residue message kernel: the
+// first two groups' weight fragments reused instead of read from LDS).
 #ifndef TMPNN_DEBUG_BUILD
-#if defined(TM_ABL_NOGELU) || defined(TM_ABL_NOSPLIT) || defined(TM_ABL_NOMFMA) || defined(TM_ABL_NOLN) || defined(TM_ABL_NOLOAD) || defined(TM_ABL_NOGAUSS)
+#if defined(TM_ABL_NOGELU) || defined(TM_ABL_NOSPLIT) || defined(TM_ABL_NOMFMA) || defined(TM_ABL_NOLN) || defined(TM_ABL_NOLOAD) || defined(TM_ABL_NOGAUSS) || defined(TM_ABL_WAVE_NOLDS)
 #error "TM_ABL_* timing ablations need -DTMPNN_DEBUG_BUILD (python -m thermompnn_amd.build --variant NAME -DTMPNN_DEBUG_BUILD -DTM_ABL_...)"
 #endif
 #endif

@@ -33,5 +33,6 @@ python tools/gap_probe.py > $O/${TAG}_gap_probe.json 2> $O/${TAG}_gap_probe.err
 python tools/gap_probe.py --gaps $(find $O/gaptrace_$TAG -name "*kernel_trace.csv" | head -1) > $O/${TAG}_gap_trace_summary.json 2>> $O/${TAG}_gaptrace.err
 rm -rf $O/gaptrace_$TAG
 python tools/margin_probe.py > $O/${TAG}_margin_probe.json 2> $O/${TAG}_margin_probe.err
+bash tools/power_probe.sh $TAG > /dev/null 2>&1      # board power / sclk beside the running bench batch -> ${TAG}_power_samples.txt
 rm -rf $O/prof_$TAG/*/*.db 2>/dev/null
 tail -c 600 $O/${TAG}_bench_full.err; head -c 400 $O/${TAG}_bench_full.json; echo; head -9 $O/${TAG}_bench_kernel_stats_timed.csv; tail -12 $O/${TAG}_pmc_traffic.log
