@@ -206,15 +206,12 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
 // it floor(T / (8 #CUs)) x 8 #CUs residues and the remainder (< 8 per workgroup) to the 8-wavefront form — which computes the same bits
 // (perm_c4, tmpnn_split.h). TM_MSG_WAVE_MIN: the smallest multiple worth a second launch and a 128 KB LDS fill per workgroup.
 #define TM_MSG_WAVE_MIN 2
-#ifndef TM_MSG_WAVE_ILV
-#define TM_MSG_WAVE_ILV 2       // accumulators whose three partial products are interleaved (see mma_wave_lds)
-#endif
+#define TM_MSG_WAVE_ILV 2       // units (accumulators) per fragment request group, their partial products interleaved term by term
 
 // acc[cb] += W[16 cb .. 16 cb + 16, :] . x over K = 128: 32 (step, block) units of 3 MFMAs; wl = the image in LDS + 16 * lane.
-// The three partial products of a unit go into ONE accumulator: back to back they run at the matrix core's LATENCY (a dependent
-// v_mfma_f32_16x16x32_f16 issues every ~32 cycles, an independent one every 16). In the 8-wavefront kernels the SIMD's other wavefront
-// is always in the same GEMM and fills the gaps; here it usually is not (first build: 38.7 cycles per MFMA), so ILV units on
-// different accumulators are interleaved term by term. Fragments: double-buffered by group of ILV units.
+// Fragments double-buffered by group of ILV units. A GEMM of 96 MFMAs takes 3 700 cycles here (38 per MFMA against 16 of pipe time)
+// WHATEVER the request depth (1 / 3 / 5 units ahead) or the interleave (1 / 2 / 4 accumulators): it is neither LDS latency nor the
+// dependence of the three products on one accumulator — the chip runs these kernels at its power limit (docs/NOTEBOOK.md 9.10).
 __device__ __forceinline__ void mma_wave_lds(const char *wl, const u4 (&x)[4][2], f4 (&acc)[8]) {
     constexpr int NS = 32, ILV = TM_MSG_WAVE_ILV, NG = NS / ILV;
     u4 w[2][ILV][2];
