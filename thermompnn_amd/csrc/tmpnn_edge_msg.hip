@@ -200,7 +200,8 @@ int launch_edge_msg_fused(const EncW &e, const float *P_edge, float *hE, const i
                           const float *W2, const float *b2, const float *P_msg, const float *mask, int64_t T, float *Ssum, float *cnt,
                           hipStream_t st) {
     EdgeArgsB a{e.W11 + 128, e.W12, e.b12, e.W13, e.b13, e.norm3_w, e.norm3_b, P_edge, hE, E_idx, (int)T,
-                tm_find_wimg(e.W11 + 128), tm_find_wimg(e.W12), tm_find_wimg(e.W13)};
+                tm_find_wimg(e.W11 + 128), tm_find_wimg(e.W12), tm_find_wimg(e.W13),
+                tm_find_wimgp(e.W11 + 128), tm_find_wimgp(e.W12), tm_find_wimgp(e.W13)};
     MsgArgsB b{W1e, ld1, W2, b2, P_msg, hE, E_idx, mask, Ssum, cnt, (int)T, tm_find_wimg(W1e), tm_find_wimg(W2), tm_find_wimgp(W1e), tm_find_wimgp(W2), 0};
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);

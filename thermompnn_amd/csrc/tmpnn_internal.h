@@ -20,8 +20,15 @@ struct DecW {
 // instead of 16-row gathers of fp32 that are split on the fly (tmpnn_split.hip: node_update8_split_kernel).
 #define TM_WIMG_BYTES 65536
 #define TM_N_WIMG 110          // enc: W3 + 4 W_in + 4 W_out + W1a W1c W11a W11c + W1e W2 W11e W12 W13 (18) x 3; dec: W3 + 4 + 4 + W1a W1d + W1e W2 (13) x 3; head: 9 blocks of the centre tap + 3 of both_out.1; featurizer: 4 blocks of W_edge[:, 16:416] + W_e
-#define TM_N_WIMGP 12          // the message kernels' W1e and W2 again (3 encoder + 3 decoder layers) with the K axis permuted inside every 32-deep step
+#define TM_N_WIMGP 21          // the message kernels' W1e and W2 (3 encoder + 3 decoder layers) again with the K axis permuted inside every 32-deep step: 12;
+                               // + room for the edge update's W11e, W12, W13 (3 layers), which only the debug library builds (tmpnn_edge_wave.hip; the
+                               // same struct layout in both libraries: A/B variants link debug objects of a few files with the shipped ones)
                                // (msg8_wave_kernel, tmpnn_msg.hip): element e of lane group q <-> k = 32 c + 16 (e >> 2) + 4 q + (e & 3)
+#ifdef TMPNN_DEBUG_BUILD
+#define TM_N_WIMGP_BUILT 21    // images a handle of THIS library builds (and its packed buffer has room for)
+#else
+#define TM_N_WIMGP_BUILT 12
+#endif
 struct WImg { const float *base; const char *img; };      // base = address of the block's element [0][0] in the raw tensor
 
 struct tmpnn_weights {
@@ -130,6 +137,10 @@ int launch_edge_msg_fused(const EncW &e, const float *P_edge, float *hE, const i
                           const float *W2, const float *b2, const float *P_msg, const float *mask, int64_t T, float *Ssum, float *cnt,
                           hipStream_t st);
 int launch_selftest(int32_t *status, hipStream_t st);
+// tmpnn_edge_wave.hip: f16x2 edge update of large launches, one wavefront per 16-row block (same bits as the 8-wavefront forms)
+struct EdgeArgsB;
+bool enc_edge_wave_wanted(int64_t T);
+int launch_enc_edge_wave(const EdgeArgsB &a, int64_t T, hipStream_t st);
 
 int tm_num_cus();
 // Kernel-form switches (TMPNN_KNN_REG, TMPNN_NODE_DEEP, TMPNN_FEAT_SPLIT ...) and the per-phase timers (TMPNN_*_PROF, which

@@ -212,10 +212,14 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
 // Fragments double-buffered by group of ILV units. A GEMM of 96 MFMAs takes 3 700 cycles here (38 per MFMA against 16 of pipe time)
 // WHATEVER the request depth (1 / 3 / 5 units ahead) or the interleave (1 / 2 / 4 accumulators): it is neither LDS latency nor the
 // dependence of the three products on one accumulator — the chip runs these kernels at its power limit (docs/NOTEBOOK.md 9.10).
-__device__ __forceinline__ void mma_wave_lds(const char *wl, const u4 (&x)[4][2], f4 (&acc)[8]) {
+// ride(G), G = 0..15: what the caller wants issued behind the six MFMAs of group G (round 6: the next block's global requests, one per
+// group — a global_load costs its wavefront ~85 cycles of issue when 17 of them stand in a row, nothing behind a group of MFMAs).
+template <typename R>
+__device__ __forceinline__ void mma_wave_lds(const char *wl, const u4 (&x)[4][2], f4 (&acc)[8], R &&ride) {
     constexpr int NS = 32, ILV = TM_MSG_WAVE_ILV, NG = NS / ILV;
     u4 w[2][ILV][2];
 #if TM_ABL_NOMFMA
+    static_for<0, NG>([&](auto G) { ride(G); });
     return;
 #endif
     auto request = [&](int g, int half) {
@@ -231,9 +235,8 @@ __device__ __forceinline__ void mma_wave_lds(const char *wl, const u4 (&x)[4][2]
     };
     request(0, 0);
 #define TM_HF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0)
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int h = g & 1;
+    static_for<0, NG>([&](auto G) {
+        constexpr int g = decltype(G)::value, h = g & 1;
         if (g + 1 < NG) request(g + 1, h ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         const u4 (&xs)[2] = x[(g * ILV) >> 3];
@@ -244,27 +247,21 @@ __device__ __forceinline__ void mma_wave_lds(const char *wl, const u4 (&x)[4][2]
 #pragma unroll
         for (int k = 0; k < ILV; ++k) acc[(g * ILV + k) & 7] = TM_HF(w[h][k][0], xs[0], acc[(g * ILV + k) & 7]);      // h h
         __builtin_amdgcn_sched_barrier(0);
-    }
+        ride(G);
+        __builtin_amdgcn_sched_barrier(0);
+    });
 #undef TM_HF
 }
-// accumulator blocks 2 c, 2 c + 1 (fp32) -> the B operand of step c
-__device__ __forceinline__ void split_pair(const f4 a, const f4 b, u4 (&x)[2]) {
-    unsigned p0[2], p1[2], p2[2], p3[2];
-    SplitH2::split2(f2{a.x, a.y}, p0);
-    SplitH2::split2(f2{a.z, a.w}, p1);
-    SplitH2::split2(f2{b.x, b.y}, p2);
-    SplitH2::split2(f2{b.z, b.w}, p3);
-    x[0] = u4{p0[0], p1[0], p2[0], p3[0]};
-    x[1] = u4{p0[1], p1[1], p2[1], p3[1]};
-}
-
 template <bool DEC, bool OFF32, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned long long *prof = nullptr) {
-    unsigned long long t_last = 0;
-    auto mark = [&](int k) {           // TMPNN_MSG_PROF=1 (debug library): phase timing of one wavefront of workgroup 0
-        if (PROF && tm_bid() == 0 && (tm_tid() & ~63) == (TM_PROF_TID & ~63) && (tm_tid() & 63) == 0) {
-            const unsigned long long t = __builtin_readcyclecounter();
-            if (k >= 0) prof[k] += t - t_last;
+    // TMPNN_MSG_PROF=1 (debug library): phase timing of one wavefront of workgroup 0 in scalar registers (s_memtime + SALU adds, written out
+    // once behind the loop — a timer that does a global read-modify-write per mark waits for every request in flight at every mark)
+    unsigned t_last = 0, t_acc[8] = {};
+    auto mark = [&](int k) {
+        if constexpr (PROF) {
+            __builtin_amdgcn_sched_barrier(0);              // (s_memtime is no scheduling barrier by itself: the phases would smear)
+            const unsigned t = (unsigned)__builtin_readcyclecounter();
+            if (k >= 0) t_acc[k] += t - t_last;
             t_last = t;
         }
     };
@@ -291,21 +288,31 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
     auto idx_of = [&](int ii, int bb) { return (a.E_idx + ((size_t)__builtin_amdgcn_readfirstlane(ii) * TM_KS + 16 * __builtin_amdgcn_readfirstlane(bb)))[(unsigned)n]; };
     f4 e_n[8], g_n[8];
     float mk_n = 1.f;
-    auto issue_block = [&](int ii, int bb, int j) {            // operands of block (ii, bb) whose list entry j has arrived
+    // operands of a block as 16 pieces: piece G rides behind MFMA group G of GEMM 1 (pieces 0..7: the gathered projection row, 16
+    // bytes per lane each; 8..15: the e rows; the mask gather goes with piece 8). Addresses are formed ONCE per block (BlockAddr).
+    struct BlockAddr { unsigned goff; const float *pj; const float *src; unsigned jj; };
+    auto block_addr = [&](int ii, int bb, int j) {
         const int jj = j < 0 ? ii : j;
-        if constexpr (OFF32) {
-            const unsigned off = (unsigned)jj * 256u + (128u + uq);
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) g_n[cb] = ld4(a.P + (off + 16u * cb));
+        BlockAddr r;
+        r.jj = (unsigned)jj;
+        r.goff = (unsigned)jj * 256u + (128u + uq);
+        r.pj = a.P + (size_t)jj * 256 + 128 + uq;
+        r.src = a.hE + ((size_t)__builtin_amdgcn_readfirstlane(ii) * TM_KS + 16 * __builtin_amdgcn_readfirstlane(bb)) * TM_H;
+        return r;
+    };
+    auto issue_piece = [&](const BlockAddr &ad, auto G) {
+        constexpr int g = decltype(G)::value;
+        if constexpr (g < 8) {
+            if constexpr (OFF32) g_n[g] = ld4(a.P + (ad.goff + 16u * g));
+            else g_n[g] = ld4(ad.pj + 16 * g);
         } else {
-            const float *pj = a.P + (size_t)jj * 256 + 128 + uq;
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) g_n[cb] = ld4(pj + 16 * cb);
+            if (g == 8 && !DEC) mk_n = a.mask[ad.jj];
+            e_n[g - 8] = ld4(ad.src + (eoff + 16u * (g - 8)));      // c = 2 step + half: columns 32 step + 16 half + 4 q
         }
-        if (!DEC) mk_n = a.mask[(unsigned)jj];
-        const float *src = a.hE + ((size_t)__builtin_amdgcn_readfirstlane(ii) * TM_KS + 16 * __builtin_amdgcn_readfirstlane(bb)) * TM_H;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) e_n[c] = ld4(src + (eoff + 16u * c));     // c = 2 step + half: columns 32 step + 16 half + 4 q
+    };
+    auto issue_block = [&](int ii, int bb, int j) {
+        const BlockAddr ad = block_addr(ii, bb, j);
+        static_for<0, 16>([&](auto G) { issue_piece(ad, G); });
     };
     f4 g0_n = f4{0.f, 0.f, 0.f, 0.f};
     float mi_n = 0.f;
@@ -317,6 +324,11 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
     int j_cur = idx_of(i, 0), j_nxt = idx_of(i, 1);
     issue_block(i, 0, j_cur);
     issue_self(i);
+    // the NEXT block's B operand: its e rows are split into planes behind MFMA groups of the current block's GEMM 2 (round 6; until
+    // then at the top of their own block, 80 vector instructions nothing else of the wavefront could hide)
+    u4 xn[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) split_pair(e_n[2 * c], e_n[2 * c + 1], xn[c]);
     f4 sum[8];
     float mi = 0.f, cnt = 0.f;
     mark(-1);
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
             u4 x[4][2];
             f4 acc[8];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) split_pair(e_n[2 * c], e_n[2 * c + 1], x[c]);
+            for (int c = 0; c < 4; ++c) { x[c][0] = xn[c][0]; x[c][1] = xn[c][1]; }
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) acc[cb] = DEC ? g_n[cb] : g_n[cb] + ld4(g0s + 16 * cb + uq);
             // consumed HERE, in front of the requests that refill e_n / g_n: left free, hipcc sinks these into the block of their first
@@ -354,7 +366,12 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
             const bool last_b = b == 2;
             const bool has1 = !last_b || more;
             const int i1 = has1 ? (last_b ? i + istep : i) : i, b1 = has1 ? (last_b ? 0 : b + 1) : b;
-            issue_block(i1, b1, has1 ? j_nxt : j_cur);
+            const BlockAddr ad1 = block_addr(i1, b1, has1 ? j_nxt : j_cur);
+            // ---- the chain; the 16 request pieces ride behind the MFMA groups of GEMM 1
+            mark(1);
+            // (pieces 2 k and 2 k + 1 read the two halves of the same sixteen 128-byte lines; issuing them together behind every other
+            //  group, so that the second finds the lines in the L1, was measured: nil — 0.1851 / 0.1857 against 0.1849 / 0.1844 ms)
+            mma_wave_lds(wl1, x, acc, [&](auto G) { issue_piece(ad1, G); });
             if (last_b) issue_self(i1);
             {
                 const bool last_b1 = b1 == 2;
@@ -363,9 +380,6 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
                 j_cur = j_nxt;
                 j_nxt = idx_of(has2 ? i2 : i1, has2 ? b2 : b1);
             }
-            // ---- the chain
-            mark(1);
-            mma_wave_lds(wl1, x, acc);
             mark(2);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -379,7 +393,10 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) acc[cb] = ld4(s_b2 + 16 * cb + uq);
             mark(3);
-            mma_wave_lds(wl2, x, acc);
+            mma_wave_lds(wl2, x, acc, [&](auto G) {              // the next block's e rows (requested behind GEMM 1) -> planes
+                constexpr int g = decltype(G)::value;
+                if constexpr (g % 3 == 0 && g >= 3 && g <= 12) split_pair(e_n[2 * (g / 3 - 1)], e_n[2 * (g / 3 - 1) + 1], xn[g / 3 - 1]);
+            });
             mark(4);
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
@@ -415,6 +432,8 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
         i += istep;
     }
     if (PROF && tm_bid() == 0 && tm_tid() == (TM_PROF_TID & ~63)) {       // shader cycles and 100 MHz ticks of the loop: the clock under THIS load
+#pragma unroll
+        for (int k = 0; k < 8; ++k) prof[k] = t_acc[k];
         prof[8] = __builtin_readcyclecounter() - c_begin;
         prof[9] = wall_clock64() - w_begin;
     }

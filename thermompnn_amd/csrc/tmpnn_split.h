@@ -19,6 +19,8 @@
 // 16 B (8 values), the chunk index XOR-ed with (row & 15): the ds_read_b128 of a B fragment (16 rows, same chunk) is
 // conflict-free.
 #pragma once
+#include <type_traits>
+
 #include "tmpnn_common.h"
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
@@ -42,6 +44,14 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 #define TM_PROF_TID 0       // thread of workgroup 0 the TMPNN_*_PROF phase timers read (448 = wavefront 7, lowest issue priority)
 #endif
 #define SPLIT_PLANE_BYTES (TM_TILE * TM_H * 2)   // one 48 x 128 plane of 16-bit values: 12288 B
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // policies
@@ -262,6 +272,44 @@ __device__ __forceinline__ void mma_tile_split(const char *tile, const WFragS<SP
         for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = SP::fold(acc[rb][cb], lo[rb][cb]);
 }
 
+// The PF > 0 form with a rider: ride(S), S = 0 .. NK32 * NRB - 1, is what the caller wants issued behind the MFMAs of step S — global
+// requests, one per step (round 6: several global_loads in a row cost their wavefront ~85 cycles of issue each; behind a step's MFMAs
+// they cost nothing). Same MFMA order as mma_tile_split: the same bits.
+template <typename SP, int NK32, int NRB, int PF, typename R>
+__device__ __forceinline__ void mma_tile_split_ride(const char *tile, const WFragS<SP> (&w)[1][NK32], f4 (&acc)[NRB][1], int lane, R &&ride) {
+    constexpr int NS = NK32 * NRB, NB = PF + 1;
+#if TM_ABL_NOMFMA
+    static_for<0, NS>([&](auto S) { ride(S); });
+    return;
+#endif
+    const int m = lane & 15, q = lane >> 4;
+    f4 lo[NRB][1];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) lo[rb][0] = f4{0.f, 0.f, 0.f, 0.f};
+    u4 x[NB][SP::NP];
+#pragma unroll
+    for (int s = 0; s < PF && s < NS; ++s)
+#pragma unroll
+        for (int p = 0; p < SP::NP; ++p)
+            x[s][p] = *reinterpret_cast<const u4 *>(tile + plane_off8<TM_TILE, 256, true>(p, 16 * (s % NRB) + m, 4 * (s / NRB) + q));
+    static_for<0, NS>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        if constexpr (s + PF < NS) {
+            constexpr int sn = s + PF;
+#pragma unroll
+            for (int p = 0; p < SP::NP; ++p)
+                x[sn % NB][p] = *reinterpret_cast<const u4 *>(tile + plane_off8<TM_TILE, 256, true>(p, 16 * (sn % NRB) + m, 4 * (sn / NRB) + q));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SP::mma(w[0][s / NRB].p, x[s % NB], acc[s % NRB][0], lo[s % NRB][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        ride(S);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = SP::fold(acc[rb][0], lo[rb][0]);
+}
+
 // One 16-row block at a time (keeps only NCB accumulator pairs live): acc[cb] += W_cb . tile[16 rb .. 16 rb + 16)^T.
 // (Interleaving the MFMA chains term by term across accumulators was measured: no gain in the kernels, -12 % in the
 // GEMM probe — back-to-back MFMAs on one accumulator do not stall on gfx950.)
@@ -408,6 +456,7 @@ struct EdgeArgsB {
     const int32_t *E_idx;
     int T;
     const char *img11, *img12, *img13;      // fragment images of the three weights (f16x2 only) or null
+    const char *imgp11, *imgp12, *imgp13;   // ... their K-permuted forms (perm_c4) or null
 };
 
 struct MsgArgsB {
@@ -423,11 +472,15 @@ struct MsgArgsB {
     int i0;                                 // first residue of this launch (a large launch = wavefront-per-residue part + a remainder)
 };
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
+// accumulator blocks 2 c, 2 c + 1 (fp32, accumulator layout) -> the f16x2 B operand of step c of the next GEMM (K order: perm_c4)
+__device__ __forceinline__ void split_pair(const f4 a, const f4 b, u4 (&x)[2]) {
+    unsigned p0[2], p1[2], p2[2], p3[2];
+    SplitH2::split2(f2{a.x, a.y}, p0);
+    SplitH2::split2(f2{a.z, a.w}, p1);
+    SplitH2::split2(f2{b.x, b.y}, p2);
+    SplitH2::split2(f2{b.z, b.w}, p3);
+    x[0] = u4{p0[0], p1[0], p2[0], p3[0]};
+    x[1] = u4{p0[1], p1[1], p2[1], p3[1]};
 }
+
 

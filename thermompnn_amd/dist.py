@@ -219,14 +219,15 @@ def agree_or_raise(err: Optional[str], group=None) -> None:
 
 
 def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, group=None, centrality: bool = False,
-               k_neighbors: Optional[int] = None, device_tables: Optional[bool] = None, **pipeline_kw):
+               k_neighbors: Optional[int] = None, device_tables: Optional[bool] = None, run_pipeline=None, **pipeline_kw):
     """PDB files -> ddG tables on rank 0, sharded over the group's GPUs, each rank running the parse || forward || copy-back
     pipeline (thermompnn_amd.pipeline.scan_files) on its LPT shard and ONE gather to rank 0 at the end.
 
     Lengths come from a strided pre-pass (rank r parses files r, r + N, ...: a few hundred microseconds per file) whose
     (length, sequence, name) triples are exchanged with ``all_gather_object``; a file that fails to parse on one rank fails
     every rank. -> rank 0: dict(table float32 [T, 21] host array in the ORIGINAL file order, offsets int64 [n+1], seqs, names,
-    neighbors int32 [T] or None, stats); other ranks: the same dict with table / neighbors = None."""
+    neighbors int32 [T] or None, stats); other ranks: the same dict with table / neighbors = None.
+    ``run_pipeline``: the function used as ``pipeline.scan_files`` (tests inject a CPU stand-in)."""
     import numpy as np
     from . import native_pdb, pipeline
     n = len(paths)
@@ -263,8 +264,8 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
 
     err, stats = None, None
     try:
-        stats = pipeline.scan_files(engine, [paths[i] for i in shard], [chains[i] for i in shard], sink, centrality=centrality,
-                                    device_table=dev_table, **pipeline_kw)
+        stats = (run_pipeline or pipeline.scan_files)(engine, [paths[i] for i in shard], [chains[i] for i in shard], sink,
+                                                      centrality=centrality, device_table=dev_table, **pipeline_kw)
     except Exception as e:               # noqa: BLE001
         err = f"rank {rank}: {type(e).__name__}: {e}"
     agree_or_raise(err, group)
@@ -275,7 +276,9 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
     else:
         lengths = [info[i][0] for i in range(n)]
         seqs, names = [info[i][1] for i in range(n)], [info[i][2] for i in range(n)]
-        assert lens_l == [lengths[i] for i in shard], "a file changed between the length pre-pass and the scan"
+        # (an agreed error, not an assert: a rank that raises alone leaves the others blocked in the gather below)
+        agree_or_raise(None if lens_l == [lengths[i] for i in shard] else
+                       f"rank {rank}: a file changed between the length pre-pass and the scan", group)
         shards = partition_proteins(lengths, world, K)
         rows = [sum(lengths[i] for i in s) for s in shards]
         if dev_table is not None:
@@ -285,6 +288,8 @@ def scan_files(engine, paths: Sequence[str], chains: Optional[Sequence] = None, 
                 loc_t = torch.cat([dev_table, cen[:, None]], dim=1)
         else:
             loc_t = torch.from_numpy(local)
+            if "nccl" in str(dist.get_backend(group)):       # RCCL moves device memory only: a host-side table (device_tables=False,
+                loc_t = loc_t.to(engine.device)              # or a mixed "cpu:gloo,cuda:nccl" group) is uploaded for the collective
         got = gather_tables_root(loc_t, rows, group, 0)
         table = None
         if got is not None:                                  # rank 0: per-rank shard tables -> the original file order
@@ -342,10 +347,71 @@ def _copy_range(src_fd: int, dst_fd: int, src_off: int, dst_off: int, n: int) ->
         src_off, dst_off, n = src_off + len(buf), dst_off + len(buf), n - len(buf)
 
 
+def default_memory_budget(local_world: Optional[int] = None) -> int:
+    """Bytes of CSV text a rank may keep in memory before it falls back to a part file: a third of the host's MemAvailable divided by the
+    ranks that share the host (LOCAL_WORLD_SIZE), at most 16 GiB. The text of a scan grows as L^2 per protein (every row repeats the
+    sequence); the mapping is MAP_NORESERVE, so without this bound the kernel would kill the process (or SIGBUS it inside memcpy) instead
+    of the scan failing cleanly or spilling to the part file."""
+    import os
+    avail = 8 << 30
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) * 1024
+                    break
+    except OSError:
+        pass
+    lw = local_world or int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0) or 1
+    return max(64 << 20, min(16 << 30, avail // (3 * lw)))
+
+
+def _csv_field_bytes(s: str) -> int:
+    """Upper bound of the bytes the native writer emits for one text field: UTF-8, embedded quotes doubled, two enclosing quotes."""
+    b = s.encode("utf-8", "surrogateescape")
+    return len(b) + b.count(b'"') + 2
+
+
+def _shared_fs_check(out: str, rank: int, world: int, group) -> Optional[str]:
+    """Every rank pwrites into ONE file: that needs a file system all ranks share. Rank 0 drops a nonce beside ``out``, everybody looks
+    for it. -> None when all ranks see it, else the agreed reason (same on every rank)."""
+    import os
+    import uuid
+    box = [uuid.uuid4().hex if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    probe = f"{out}.{box[0]}.probe"
+    err = None
+    if rank == 0:
+        try:
+            with open(probe, "w") as f:
+                f.write(box[0])
+        except OSError as e:
+            err = f"rank 0: cannot write beside {out}: {e}"
+    dist.barrier(group=group)
+    seen = False
+    try:
+        with open(probe) as f:
+            seen = f.read() == box[0]
+    except OSError:
+        pass
+    flags = [None] * world
+    dist.all_gather_object(flags, (seen, err), group=group)
+    if rank == 0:
+        try:
+            os.remove(probe)
+        except OSError:
+            pass
+    errs = [e for _, e in flags if e]
+    if errs:
+        return errs[0]
+    blind = [r for r, (ok, _) in enumerate(flags) if not ok]
+    return None if not blind else f"ranks {blind} do not see rank 0's files beside {out} (no shared file system)"
+
+
 def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], out: str, model_name: str = "ThermoMPNN",
                       dataset: str = "custom", pick_best: bool = False, include_cys: bool = False, centrality: bool = False,
                       group=None, k_neighbors: Optional[int] = None, n_threads: int = 0, run_pipeline=None,
-                      max_part_bytes: int = 64 << 30, **pipeline_kw):
+                      max_part_bytes: Optional[int] = None, shared_fs: Optional[bool] = None, **pipeline_kw):
     """PDB files -> ONE CSV in the reference's layout (analysis/SSM.py:102-176), every rank FORMATTING its own shard (round 5; until
     round 4 every table went to rank 0, which formatted the whole listing alone: one writer does 7-17 M predictions/s against
     > 100 M/s per GPU, so an 8-GPU scan to CSV ran at the one-GPU rate).
@@ -360,7 +426,15 @@ def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], 
          copy_file_range from the part file).
     The result is byte-identical to the one-rank file (tests: world-2 gloo with a stand-in pipeline on CPU, two ranks on one GPU
     with the real engine). ``run_pipeline``: the function used as ``pipeline.scan_files`` (tests inject a CPU stand-in).
-    -> (rows, stats) on every rank (rows = of the whole file)."""
+    -> (rows, stats) on every rank (rows = of the whole file).
+
+    Memory: a rank keeps its shard's text (about 411 bytes per prediction for L = 256: every row repeats the sequence) in an anonymous
+    mapping up to ``max_part_bytes`` (default ``default_memory_budget()``: a third of MemAvailable / LOCAL_WORLD_SIZE, at most 16 GiB);
+    larger shards — or a mapping the kernel refuses — go to a part file beside ``out``.
+    File system: every rank opens ``out``, so all ranks must share a coherent file system (one node, or a POSIX-coherent parallel file
+    system; NFS gives weak guarantees for unlocked concurrent range writes). ``shared_fs``: None = probe it (rank 0 drops a nonce
+    beside ``out``) and fall back to the gather-to-rank-0 writer (``scan_files`` + one writer) when a rank does not see it; False =
+    that fallback at once; True = no probe."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     import numpy as np
@@ -376,6 +450,23 @@ def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], 
         from . import ssm_scan
         return ssm_scan.scan_to_file(engine, paths, chains, out, model_name, dataset, pick_best, include_cys, centrality,
                                      n_threads=nt, **pipeline_kw)
+    why = "shared_fs=False" if shared_fs is False else (None if shared_fs else _shared_fs_check(out, rank, world, group))
+    if why is not None:                                      # one writer: every table to rank 0 (what rounds 3-4 did for every scan)
+        from . import ssm_scan
+        r = scan_files(engine, paths, chains, group=group, centrality=centrality, k_neighbors=k_neighbors, run_pipeline=run_pipeline,
+                       device_tables=False if run_pipeline is not pipeline.scan_files else None, **pipeline_kw)
+        rows, err = 0, None
+        if rank == 0:
+            try:
+                rows = ssm_scan.write_scan_csv(out, r, model_name, dataset, pick_best, include_cys, None, n_threads=nt)
+            except Exception as e:       # noqa: BLE001
+                err = f"rank 0: {type(e).__name__}: {e}"
+        agree_or_raise(err, group)
+        box = [rows]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return int(box[0]), r["stats"]
+    if max_part_bytes is None:
+        max_part_bytes = default_memory_budget()
     info = _length_prepass(paths, chains, rank, world, group)
     lengths = [info[i][0] for i in range(n)]
     shard = partition_proteins(lengths, world, K)[rank]
@@ -385,16 +476,22 @@ def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], 
     # this rank's text stays in MEMORY (an anonymous, huge-page-backed mapping) until the byte counts are exchanged: a part file beside
     # ``out`` pays the file system's page allocation twice, and that allocation — not the formatting — is what bounds the CSV sink
     # (bench.py: tmpfs_write_ceiling). Address space for an upper bound of the shard's text; beyond ``max_part_bytes`` a part file.
-    name_len = lambda i: len(info[i][2])
-    bound = sum(rows_of[i] * (len(info[i][1]) + len(model_name) + len(dataset) + 2 * name_len(i) + 96) for i in shard) + (1 << 16)
+    # (bytes as the writer emits them: UTF-8, quotes doubled + two enclosing ones; the name appears twice in --pick_best rows)
+    fixed = _csv_field_bytes(model_name) + _csv_field_bytes(dataset)
+    bound = sum(rows_of[i] * (_csv_field_bytes(info[i][1]) + fixed + 2 * _csv_field_bytes(info[i][2].strip(".pdb")) + 96) for i in shard) + (1 << 16)
     in_memory = bound <= max_part_bytes
     part = f"{out}.part{rank}"
     nbytes = {}
     err, stats = None, None
     w = None
     try:
-        w = (native_csv.CsvWriter(None, native_csv.SCHEMA_SSM, pick_best=pick_best, memory_capacity=bound) if in_memory else
-             native_csv.CsvWriter(part, native_csv.SCHEMA_SSM, header=False, pick_best=pick_best))
+        if in_memory:
+            try:
+                w = native_csv.CsvWriter(None, native_csv.SCHEMA_SSM, pick_best=pick_best, memory_capacity=bound)
+            except (OSError, MemoryError, RuntimeError):     # the kernel refused the mapping: the part file instead
+                in_memory = False
+        if not in_memory:
+            w = native_csv.CsvWriter(part, native_csv.SCHEMA_SSM, header=False, pick_best=pick_best)
         done = [0]
 
         def sink(ch):
@@ -419,6 +516,8 @@ def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], 
         dist.all_gather_object(parts, nbytes, group=group)
         allb = {k: v for p in parts for k, v in p.items()}
         hdr = native_csv.header_text(native_csv.SCHEMA_SSM, pick_best)
+        missing = [i for i in range(n) if i not in allb]
+        agree_or_raise(f"no rank reported the text of proteins {missing[:8]}" if missing else None, group)   # (same verdict on every rank)
         offs = np.concatenate([[len(hdr)], len(hdr) + np.cumsum([allb[i] for i in range(n)])]).astype(np.int64)
         err = None
         if rank == 0:
@@ -463,8 +562,8 @@ def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], 
                 os.close(dst)
                 if src >= 0:
                     os.close(src)
-        except OSError as e:
-            err = f"rank {rank}: {e}"
+        except Exception as e:           # noqa: BLE001 (anything: a rank that raises alone leaves the others in the collective below)
+            err = f"rank {rank}: {type(e).__name__}: {e}"
         agree_or_raise(err, group)
     finally:
         if w is not None and in_memory:
@@ -473,10 +572,11 @@ def scan_files_to_csv(engine, paths: Sequence[str], chains: Optional[Sequence], 
                 w.close()
             except Exception:                                # noqa: BLE001
                 pass
-        try:
-            os.remove(part)
-        except OSError:
-            pass
+        if not in_memory:
+            try:
+                os.remove(part)
+            except OSError:
+                pass
     return int(first_row[-1]), stats
 
 

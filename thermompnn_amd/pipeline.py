@@ -107,7 +107,7 @@ class Chunk:
     row0: int = 0                    # first row of this chunk in the scan's packed residue axis (= its rows of ``device_table``)
 
     def seqs(self) -> List[str]:
-        return [C.string_at(p).decode() for p in self.seq_ptrs]
+        return [p if isinstance(p, str) else C.string_at(p).decode() for p in self.seq_ptrs]      # (tests hand the sink plain strings)
 
 
 @dataclass

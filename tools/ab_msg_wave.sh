@@ -2,7 +2,7 @@
 # The wavefront-per-residue message pass against its 8-wavefront form, and what its parts cost, in ONE gpurun call (round 5,
 # docs/NOTEBOOK.md 9.10-9.11). All variants are debug builds of tmpnn_msg.hip only; results of the ablations are wrong by construction.
 #   tools/ab_msg_wave.sh build      (here, no GPU needed)   -> thermompnn_amd/libtmpnn_mw_*.so
-#   tools/ab_msg_wave.sh run        (on the GPU box)        -> gpurun_out/${TAG:-r05}_ab_msg_wave.txt
+#   tools/ab_msg_wave.sh run        (on the GPU box)        -> gpurun_out/${TAG:-r06}_ab_msg_wave.txt
 # Per variant: per-kernel HIP-event times of the bench batch (tools/ab_time.py) and, from the kernel's own counters, the shader clock
 # it ran at (TMPNN_MSG_PROF=1: cycle counter against the 100 MHz reference around one wavefront's loop, after 40 forwards).
 cd "$(dirname "$0")/.."
@@ -27,6 +27,6 @@ run)
     echo "## 8-wavefront form again (alternation)"
     TMPNN_LIB=${L}_shipped.so TMPNN_MSG_WAVE_MIN=1000000 python tools/ab_time.py 8wavefront
     echo "## shipped again"
-    TMPNN_LIB=${L}_shipped.so python tools/ab_time.py shipped; } 2>&1 | grep -v "amdgpu.ids" | tee gpurun_out/${TAG:-r05}_ab_msg_wave.txt ;;
+    TMPNN_LIB=${L}_shipped.so python tools/ab_time.py shipped; } 2>&1 | grep -v "amdgpu.ids" | tee gpurun_out/${TAG:-r06}_ab_msg_wave.txt ;;
 *) echo "usage: $0 build|run" ;;
 esac

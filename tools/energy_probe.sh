@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/probe/mfma_energy_probe (one instruction class at a time, all CUs, ~1 s each) with rocm-smi power / sclk sampled beside it
-# (run on the GPU box) -> gpurun_out/${1:-r05}_energy_probe.txt
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r05}_energy_probe.txt
+# (run on the GPU box) -> gpurun_out/${1:-r06}_energy_probe.txt
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r06}_energy_probe.txt
 cd $R; mkdir -p gpurun_out
 ( tools/probe/mfma_energy_probe > $O.probe 2>&1 & )
 sleep 0.5

@@ -5,7 +5,7 @@ Compiles every .hip of thermompnn_amd/csrc to gfx950 assembly with the flags of 
 (hipcc --offload-device-only -S), finds in each kernel the largest loop (the persistent tile loop: the backward branch whose
 span holds the most instructions) and counts what one wavefront issues per trip: MFMA by shape, VALU (packed, transcendental
 and the rest separately — they issue at different rates), SALU, LDS, vector memory, barriers / waits.
-    python tools/isa_counts.py [out.json]        (default profiles/r05_isa_counts.json; needs hipcc, no GPU)
+    python tools/isa_counts.py [out.json]        (default profiles/r06_isa_counts.json; needs hipcc, no GPU)
 The file is stamped with the hash of the kernel sources: bench.py ignores a file measured on other sources."""
 import json
 import os
@@ -121,7 +121,7 @@ def demangle(names):
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "profiles", "r05_isa_counts.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "profiles", "r06_isa_counts.json")
     import bench
     res = {"source_stamp": bench.kernel_source_stamp(), "flags": tm_build.FLAGS, "kernels": {}}
     with tempfile.TemporaryDirectory() as tmp:

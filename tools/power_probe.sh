@@ -1,8 +1,8 @@
 #!/bin/bash
 # What the board reports while the bench batch runs back to back (run on the GPU box): rocm-smi power / clocks / temperature sampled once a
-# second beside ~12 s of forwards, then once more idle -> gpurun_out/${1:-r05}_power_samples.txt. The evidence behind "the pipeline is
+# second beside ~12 s of forwards, then once more idle -> gpurun_out/${1:-r06}_power_samples.txt. The evidence behind "the pipeline is
 # power-limited" other than the kernel's own cycle counter (docs/NOTEBOOK.md 9.10).
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r05}_power_samples.txt
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r06}_power_samples.txt
 cd $R; mkdir -p gpurun_out
 sample() { (rocm-smi --showpower --showclocks --showtemp --showperflevel --showmaxpower 2>&1 || amd-smi metric -p -c -t 2>&1) | grep -v "^$" | grep -iv "^=\|WARNING" | head -40; }
 { echo "### idle, before"; sample
