@@ -1,4 +1,4 @@
-// Edge update of an encoder layer (protein_mpnn_utils.py:826-839), split-precision forms: f16x2 = enc_edge8_rp_kernel, bf16x3 = enc_edge8_split_kernel.
+// Edge update of an encoder layer (protein_mpnn_utils.py:826-839), split-precision form: enc_edge8_rp_kernel (f16x2 and bf16x3).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -8,147 +8,8 @@
 #include "tmpnn_internal.h"
 
 // ------------------------------------------------------------------------------------------------
-// enc_edge, split-precision form (8 wavefronts, 1 workgroup per CU): same pipeline as enc_edge8_kernel
-// (tmpnn_layers.hip) with the three 128x128 GEMMs on the 16-bit matrix cores. GEMM inputs live in LDS as plane tiles;
-// the LayerNorm input is an fp32 tile aliased on the x planes. The next residue's fp32 tile lands in an LDS staging
-// buffer by LDS-DMA under GEMM 1 and is split into the e planes during the LayerNorm/store phase. Residual: bf16x3
-// re-joins the e planes (exact); f16x2 keeps the fp32 tile (two staging buffers, alternating).
-// ------------------------------------------------------------------------------------------------
-template <typename SP>
-__global__ __launch_bounds__(512, 2) void enc_edge8_split_kernel(EdgeArgsB a) {
-    constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
-    constexpr int NST = SP::EXACT ? 1 : 2;                               // fp32 staging buffers
-    static_assert(TILEB >= TM_TILE * TM_H * 4, "the fp32 LayerNorm tile is aliased on the x planes");
-    __shared__ __attribute__((aligned(16))) char tE[TILEB];
-    __shared__ __attribute__((aligned(16))) char tX[TILEB];              // x planes; later the fp32 LayerNorm input
-    __shared__ __attribute__((aligned(16))) char tY[TILEB];
-    __shared__ __attribute__((aligned(16))) float tStageB[NST][TM_TILE * TM_H]; // fp32 tiles landed by LDS-DMA
-    __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT8_LD];
-    __shared__ int s_idx[2][TM_TILE];
-    float *tO = reinterpret_cast<float *>(tX);
-    const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-
-    WFragS<SP> w11[1][4], w12[1][4], w13[1][4];
-    load_wfrag_split<SP, 4>(a.W11e, 384, 16 * wv, 0, TM_H, w11[0], lane);
-    load_wfrag_split<SP, 4>(a.W12, TM_H, 16 * wv, 0, TM_H, w12[0], lane);
-    load_wfrag_split<SP, 4>(a.W13, TM_H, 16 * wv, 0, TM_H, w13[0], lane);
-    const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
-    const int c32 = lane & 31;
-
-    // linear (unswizzled) LDS-DMA of one fp32 tile: 24 wave-instructions of 1 KB, three per wavefront
-    auto stage_async = [&](const float *src, float *tStage) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int blk = 3 * wv + k;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + blk * 256 + lane * 4),
-                                             (__attribute__((address_space(3))) void *)(tStage + blk * 256), 16, 0, 0);
-        }
-    };
-    auto split_stage = [&](const float *tStage) {      // tStage (fp32, linear) -> e planes
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int idx = it * 512 + tid;
-            store_split<SP>(tE, idx >> 5, idx & 31, ld4(tStage + idx * 4));
-        }
-    };
-
-    const TileRange tr = xcd_tile_range(a.T);
-    int i = tr.begin;
-    int cur = 0, sb = 0;                               // s_idx buffer / staging buffer of the current tile
-    f4 gai, gcj[3];
-    if (i < tr.end) {
-        if (tid < TM_TILE) s_idx[0][tid] = a.E_idx[(size_t)i * TM_KS + tid];
-        stage_async(a.hE + (size_t)i * TM_KS * TM_H, tStageB[0]);
-        __syncthreads();
-        split_stage(tStageB[0]);
-        gai = ld4(a.P + (size_t)i * 256 + ncol);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const int j = s_idx[0][16 * rb + m];
-            gcj[rb] = ld4(a.P + (size_t)(j < 0 ? i : j) * 256 + 128 + ncol);
-        }
-        __syncthreads();
-    }
-    for (; i < tr.end; i += tr.step) {
-        float *tile_g = a.hE + (size_t)i * TM_KS * TM_H;
-        const int inext = i + tr.step;
-        const bool has_next = inext < tr.end;
-        int nidx = -1;
-        const int sn = NST == 2 ? sb ^ 1 : 0;
-        if (has_next) {
-            stage_async(a.hE + (size_t)inext * TM_KS * TM_H, tStageB[sn]);
-            if (tid < TM_TILE) nidx = a.E_idx[(size_t)inext * TM_KS + tid];
-        }
-        f4 acc[3][1];
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
-        mma_tile_split<SP, 4, 1>(tE, w11, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            store_split<SP>(tX, 16 * rb + m, c4, gelu4(acc[rb][0]));
-            __builtin_amdgcn_sched_barrier(0);      // one row block at a time: keeps the GELU temporaries out of the weight VGPRs
-        }
-        if (has_next && tid < TM_TILE) s_idx[cur ^ 1][tid] = nidx;
-        __syncthreads();
-
-        if (has_next) {
-            gai = ld4(a.P + (size_t)inext * 256 + ncol);
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) {
-                const int j = s_idx[cur ^ 1][16 * rb + m];
-                gcj[rb] = ld4(a.P + (size_t)(j < 0 ? inext : j) * 256 + 128 + ncol);
-            }
-        }
-        {
-            const f4 b12 = ld4(a.b12 + ncol);
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
-        }
-        mma_tile_split<SP, 4, 1>(tX, w12, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            store_split<SP>(tY, 16 * rb + m, c4, gelu4(acc[rb][0]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-
-        {
-            const f4 b13 = ld4(a.b13 + ncol);
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
-        }
-        mma_tile_split<SP, 4, 1>(tY, w13, acc, lane);
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            const int row = 16 * rb + m;
-            const f4 e = SP::EXACT ? load_joined<SP>(tE, row, c4)            // residual: exact re-join of the e planes
-                                   : ld4(tStageB[sb] + row * TM_H + 4 * c4); //           or the fp32 tile itself
-            const f4 v = e + acc[rb][0];
-            st4(tO + chunk_off(16 * rb + m, c4), v);
-            row_stats_partial1b(v, &s_stat[16 * rb + m][2 * wv], q);
-        }
-        __syncthreads();                                                     // tE free, tO + stats complete
-
-        if (has_next) split_stage(tStageB[sn]);
-        {
-            const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
-#pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int row = 6 * wv + 2 * it + (lane >> 5);
-                float mean, rstd;
-                row_stats_finish8b(&s_stat[row][0], mean, rstd);
-                const f4 y = (ld4(tO + chunk_off(row, c32)) - mean) * rstd * g4 + be4;
-                if (s_idx[cur][row] >= 0) st4(tile_g + (size_t)row * TM_H + 4 * c32, y);
-            }
-        }
-        cur ^= 1;
-        sb = sn;
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// enc_edge, register-prefetch form (used for f16x2, which leaves the VGPRs for it): the next residue's fp32 tile is
+// enc_edge, register-prefetch form (both split precisions since round 6; bf16x3 with its own budget, see SP::EXACT below — until
+// then it staged the tile through LDS-DMA + an fp32 LDS tile, 139 KB of LDS and 0.58 ms per launch of the bench batch): the next residue's fp32 tile is
 // loaded straight into the accumulator layout (row 16 rb + m, columns 16 wv + 4 q: one 16-byte load per row block)
 // at the top of the iteration, split into the e planes after GEMM 3 and kept in registers as the fp32 residual of the
 // next iteration. No LDS staging, no LDS-DMA (whose conservative vmcnt(0) waits serialised the store phase), biases and
@@ -172,7 +33,11 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     // GEMM 2's output planes live where the e planes were: GEMM 1 was their last reader (every wavefront is past the barrier behind
     // it), the next tile's e planes are written only behind the barrier that follows GEMM 3. Two plane tiles instead of three:
     // 53 KB of LDS, every LDS offset below 64 KB (an offset above costs an address VGPR + a v_or each: 10 VALU per tile).
-    char *const tY = tE;
+    // bf16x3 (round 6): its three planes re-join exactly, so the e planes ARE the residual (no fp32 copy of the tile in registers) and GEMM 2's
+    // output gets a tile of its own (3 x 36 KB of LDS); the per-column parameters come from LDS. 48 weight VGPRs per matrix leave no room otherwise.
+    __shared__ __attribute__((aligned(16))) char tY3[SP::EXACT ? TILEB : 16];
+    char *const tY = SP::EXACT ? tY3 : tE;
+    __shared__ __attribute__((aligned(16))) float s_par[SP::EXACT ? 4 : 1][TM_H];
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT_LD];
     __shared__ int s_idx[2][TM_TILE];
     float *tO = reinterpret_cast<float *>(tX);
@@ -192,8 +57,15 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         if constexpr (OFF32) return a.P + ((unsigned)jj * 256u + (128u + ucol));
         else return a.P + (size_t)jj * 256 + 128 + ncol;
     };
-    const f4 b12 = ld4(a.b12 + ncol), b13 = ld4(a.b13 + ncol);
-    const f4 g4 = ld4(a.g3 + 4 * c32), be4 = ld4(a.be3 + 4 * c32);
+    constexpr int EPF = SP::EXACT ? 1 : TM_EDGE_PF;                      // B-fragment prefetch distance (three planes per fragment in bf16x3)
+    f4 b12r, b13r, g4r, be4r;
+    if constexpr (SP::EXACT) {
+        if (tid < 128) st4(&s_par[tid >> 5][4 * (tid & 31)], ld4((tid < 32 ? a.b12 : tid < 64 ? a.b13 : tid < 96 ? a.g3 : a.be3) + 4 * (tid & 31)));
+    } else {
+        b12r = ld4(a.b12 + ncol); b13r = ld4(a.b13 + ncol);
+        g4r = ld4(a.g3 + 4 * c32); be4r = ld4(a.be3 + 4 * c32);
+    }
+    auto par = [&](int k, int col, const f4 &reg) -> f4 { if constexpr (SP::EXACT) return ld4(&s_par[k][col]); else return reg; };
 
     const TileRange tr = xcd_tile_range(a.T);
     int i = tr.begin;
@@ -235,13 +107,13 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         f4 acc[3][1];
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
-        mma_tile_split_ride<SP, 4, 3, TM_EDGE_PF>(tE, w11, acc, lane, [&](auto S) {
+        mma_tile_split_ride<SP, 4, 3, EPF>(tE, w11, acc, lane, [&](auto S) {
             constexpr int s = decltype(S)::value;
             if constexpr (s == 1) { if (tid < TM_TILE) nidx = a.E_idx[(size_t)ipf2 * TM_KS + tid]; }
 #if TM_ABL_NOLOAD
             if constexpr (s % 3 == 0 && s >= 3) e_nxt[s / 3 - 1] = e_cur[s / 3 - 1];
 #else
-            if constexpr (s % 3 == 0 && s >= 3) e_nxt[s / 3 - 1] = ld4(src + (eoff + 16 * (s / 3 - 1) * TM_H));
+            if constexpr (!SP::EXACT && s % 3 == 0 && s >= 3) e_nxt[s / 3 - 1] = ld4(src + (eoff + 16 * (s / 3 - 1) * TM_H));
 #endif
         });
         mark(0);
@@ -259,12 +131,18 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         mark(2);
 
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = par(0, ncol, b12r);
         // ... and its gathered node terms behind the MFMAs of GEMM 2 (the list they need was published in front of the barrier above)
-        mma_tile_split_ride<SP, 4, 3, TM_EDGE_PF>(tX, w12, acc, lane, [&](auto S) {
+        // (bf16x3, 48 weight VGPRs per matrix: every request one phase later — the e rows behind GEMM 2, the gathers behind GEMM 3's end —
+        //  so that the 28 registers they land in are not all live through the three GEMMs)
+        mma_tile_split_ride<SP, 4, 3, EPF>(tX, w12, acc, lane, [&](auto S) {
             constexpr int s = decltype(S)::value;
-            if constexpr (s == 1) gai = ld4(a.P + (size_t)ipf * 256 + ucol);
-            if constexpr (s % 3 == 0 && s >= 3) gcj[s / 3 - 1] = ld4(prow_of(s_idx[cur ^ 1][16 * (s / 3 - 1) + m], ipf));
+            if constexpr (SP::EXACT) {
+                if constexpr (s % 3 == 0 && s >= 3) e_nxt[s / 3 - 1] = ld4(src + (eoff + 16 * (s / 3 - 1) * TM_H));
+            } else {
+                if constexpr (s == 1) gai = ld4(a.P + (size_t)ipf * 256 + ucol);
+                if constexpr (s % 3 == 0 && s >= 3) gcj[s / 3 - 1] = ld4(prow_of(s_idx[cur ^ 1][16 * (s / 3 - 1) + m], ipf));
+            }
         });
         mark(3);
         {
@@ -280,12 +158,19 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         mark(5);
 
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
-        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tY, w13, acc, lane);
+        for (int rb = 0; rb < 3; ++rb) acc[rb][0] = par(1, ncol, b13r);
+        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, EPF>(tY, w13, acc, lane);
+        if constexpr (SP::EXACT) {
+            gai = ld4(a.P + (size_t)ipf * 256 + ucol);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) gcj[rb] = ld4(prow_of(s_idx[cur ^ 1][16 * rb + m], ipf));
+        }
         mark(6);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
-            const f4 v = e_cur[rb] + acc[rb][0];                             // residual on the fp32 tile
+            f4 v;                                                            // residual: the fp32 tile, or (bf16x3) the exact re-join of its planes
+            if constexpr (SP::EXACT) v = load_joined<SP>(tE, 16 * rb + m, c4) + acc[rb][0];
+            else v = e_cur[rb] + acc[rb][0];
             st4(tO + chunk_off(16 * rb + m, c4), v);
 #if TM_ABL_NOLN
             (void)q;
@@ -314,6 +199,7 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
 #endif
             // (x - mean) rstd g + be as y = x s + t with s = rstd g, t = be - mean s: three packed fmas / muls per half row
             const f4 x4 = ld4(tO + chunk_off(row, c32));
+            const f4 g4 = par(2, 4 * c32, g4r), be4 = par(3, 4 * c32, be4r);
             const f2 s01 = f2{g4.x, g4.y} * rstd, s23 = f2{g4.z, g4.w} * rstd;
             const f2 t01 = __builtin_elementwise_fma(f2{-mean, -mean}, s01, f2{be4.x, be4.y});
             const f2 t23 = __builtin_elementwise_fma(f2{-mean, -mean}, s23, f2{be4.z, be4.w});
@@ -342,7 +228,10 @@ int launch_enc_edge_split(int mode, const EncW &e, const float *P, float *hE, co
     if (h2 && a.imgp11 && a.imgp12 && a.imgp13 && enc_edge_wave_wanted(T)) return launch_enc_edge_wave(a, T, st);
     const int64_t cap = tm_num_cus();
     const int grid = (int)(T < cap ? T : cap);
-    if (mode == TM_MM_BF16X3) enc_edge8_split_kernel<SplitBF3><<<grid, 512, 0, st>>>(a);
+    if (mode == TM_MM_BF16X3) {
+        if (T < ((int64_t)1 << 22)) enc_edge8_rp_kernel<SplitBF3, false, true><<<grid, 512, 0, st>>>(a);
+        else enc_edge8_rp_kernel<SplitBF3><<<grid, 512, 0, st>>>(a);
+    }
     else {
 #ifdef TMPNN_DEBUG_BUILD
         static const bool prof = TM_DBG_FLAG("TMPNN_EDGE_PROF", false);
