@@ -133,16 +133,26 @@ __global__ __launch_bounds__(512, 2) void msg8_rp_kernel(MsgArgsB a, unsigned lo
         // tile after the next. The gathers are waited for at the end of this iteration; were they younger than the tile
         // loads, that wait would also force the tile loads home after one GEMM phase instead of one full iteration (an HBM
         // round trip under load is longer than a phase: ablation showed only 0.02 of the 0.09 ms of e-tile streaming hidden).
-        gather(ipf, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);                       // (hipcc hoisted the tile request above the gathers: the wait for the
-                                                                 //  gathers at the end of the iteration then drained it too — vmcnt(0))
-#if !TM_ABL_NOLOAD
-        fetch_tile(ipf + tr.step < tr.end ? ipf + tr.step : ipf);
-#endif
+        // Round 6: the seven requests ride one by one behind the MFMA steps of GEMM 2, in that order (in a row in front of it they
+        // cost the wavefront ~85 cycles of issue each).
+        const int ipf3 = ipf + tr.step < tr.end ? ipf + tr.step : ipf;
+        const float *src3 = a.hE + (size_t)__builtin_amdgcn_readfirstlane(ipf3) * (TM_KS * TM_H);
         mark(3);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = bias2;
-        mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tA, w2, acc, lane);
+        mma_tile_split_ride<SP, 4, 3, TM_MSG_PF>(tA, w2, acc, lane, [&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if constexpr (s == 0) g0 = ld4(a.P + (size_t)__builtin_amdgcn_readfirstlane(ipf) * 256 + ucol);
+            if constexpr (s >= 1 && s <= 3) {
+                const int j0 = s_idx[cur ^ 1][16 * (s - 1) + m];
+                const int j = j0 < 0 ? ipf : j0;
+                if constexpr (OFF32) gj[s - 1] = ld4(a.P + ((unsigned)j * 256u + (128u + ucol)));
+                else gj[s - 1] = ld4(a.P + (size_t)j * 256 + 128 + ncol);
+            }
+#if !TM_ABL_NOLOAD
+            if constexpr (s >= 5 && s <= 9 && (s & 1)) e_nxt[(s - 5) >> 1] = ld4(src3 + (eoff + 2 * ((s - 5) >> 1) * TM_H));
+#endif
+        });
         mark(4);
         f4 tot = f4{0.f, 0.f, 0.f, 0.f};                         // masked sum over the K neighbours, in registers
 #pragma unroll
