@@ -380,6 +380,22 @@ __global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsi
         }
     };
     static_for<0, D>(issue);
+    // round 6: behind the prologue the fragment requests ride two by two behind the four MFMA steps of the unit being multiplied
+    // (eight global_loads in a row cost their wavefront ~85 cycles of issue each — as long as the unit's MFMAs)
+    auto issue_piece = [&](auto P, auto K) {
+        constexpr int p = decltype(P)::value, k = decltype(K)::value;
+        if constexpr (p < NPOS) {
+            const char *src = a.img[unit_at(p)] + (size_t)wv * 8192 + lane * 16;
+            ring[p % NS][0][k >> 1].p[k & 1] = *reinterpret_cast<const u4 *>(src + 2048 * (k >> 1) + 1024 * (k & 1));
+        }
+    };
+    auto gemm = [&](const char *plane, auto PU, auto PI, f4 (&ac)[1][1]) {      // unit PU from its ring slot; the pieces of position PI ride
+        mma_tile_split_ride<SP, 4, 1, TM_NODE_DEEP_PF, ROWS>(plane, ring[decltype(PU)::value % NS], ac, lane, [&](auto S) {
+            constexpr int s = decltype(S)::value;
+            issue_piece(PI, std::integral_constant<int, 2 * s>{});
+            issue_piece(PI, std::integral_constant<int, 2 * s + 1>{});
+        });
+    };
     // (the masks use the loaded values: in front of the ring they would make it wait for them)
     const f4 sv = ok_h ? sv_raw : z4, hv = ok_m ? hv_raw : z4;
     const float cnt = ok_m ? cnt_raw : 0.f, mk = ok_h ? mk_raw : 0.f;
@@ -398,9 +414,8 @@ __global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsi
     mark();
 
     f4 acc[1][1];
-    issue(std::integral_constant<int, D>{});
     acc[0][0] = z4;
-    mma_tile_split<SP, 4, 1, 1, ROWS, 256, 4, 0, true, TM_NODE_DEEP_PF>(pA, ring[0], acc, lane);             // W3
+    gemm(pA, std::integral_constant<int, 0>{}, std::integral_constant<int, D>{}, acc);                       // W3
     {
         const f4 dh = fma4s(cnt, b3, acc[0][0]) / 30.0f;
         st4(tB + chunk_off(m, c4), hv + dh);
@@ -420,14 +435,12 @@ __global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsi
     out[0][0] = bout;
     static_for<0, 4>([&](auto C) {                              // FFN hidden 512 in four 128-wide chunks
         constexpr int c = decltype(C)::value;
-        issue(std::integral_constant<int, 1 + 2 * c + D>{});
         acc[0][0] = bin[c];
-        mma_tile_split<SP, 4, 1, 1, ROWS, 256, 4, 0, true, TM_NODE_DEEP_PF>(pB, ring[(1 + 2 * c) % NS], acc, lane);
+        gemm(pB, std::integral_constant<int, 1 + 2 * c>{}, std::integral_constant<int, 1 + 2 * c + D>{}, acc);
         store_split<SP, ROWS>(pA, m, c4, gelu4(acc[0][0]));
         __syncthreads();
         mark();
-        issue(std::integral_constant<int, 2 + 2 * c + D>{});
-        mma_tile_split<SP, 4, 1, 1, ROWS, 256, 4, 0, true, TM_NODE_DEEP_PF>(pA, ring[(2 + 2 * c) % NS], out, lane);
+        gemm(pA, std::integral_constant<int, 2 + 2 * c>{}, std::integral_constant<int, 2 + 2 * c + D>{}, out);
         __syncthreads();
         mark();
     });
@@ -447,9 +460,8 @@ __global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsi
         __syncthreads();
         static_for<0, 2 * NPROJ>([&](auto J) {
             constexpr int j = decltype(J)::value, k = j >> 1, half = j & 1;
-            issue(std::integral_constant<int, 9 + j + D>{});
             acc[0][0] = half ? z4 : pb[k];
-            mma_tile_split<SP, 4, 1, 1, ROWS, 256, 4, 0, true, TM_NODE_DEEP_PF>(pB, ring[(9 + j) % NS], acc, lane);
+            gemm(pB, std::integral_constant<int, 9 + j>{}, std::integral_constant<int, 9 + j + D>{}, acc);
             if (ok_m) {
                 float *dst = a.proj[pk[k]].P + (size_t)row_m * 256 + 128 * half + ncol;
                 st4(dst, half && has_add[k] ? padd[k] + acc[0][0] : acc[0][0]);

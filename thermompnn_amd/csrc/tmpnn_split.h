@@ -275,7 +275,7 @@ __device__ __forceinline__ void mma_tile_split(const char *tile, const WFragS<SP
 // The PF > 0 form with a rider: ride(S), S = 0 .. NK32 * NRB - 1, is what the caller wants issued behind the MFMAs of step S — global
 // requests, one per step (round 6: several global_loads in a row cost their wavefront ~85 cycles of issue each; behind a step's MFMAs
 // they cost nothing). Same MFMA order as mma_tile_split: the same bits.
-template <typename SP, int NK32, int NRB, int PF, typename R>
+template <typename SP, int NK32, int NRB, int PF, int ROWS = TM_TILE, typename R>
 __device__ __forceinline__ void mma_tile_split_ride(const char *tile, const WFragS<SP> (&w)[1][NK32], f4 (&acc)[NRB][1], int lane, R &&ride) {
     constexpr int NS = NK32 * NRB, NB = PF + 1;
 #if TM_ABL_NOMFMA
@@ -291,14 +291,14 @@ __device__ __forceinline__ void mma_tile_split_ride(const char *tile, const WFra
     for (int s = 0; s < PF && s < NS; ++s)
 #pragma unroll
         for (int p = 0; p < SP::NP; ++p)
-            x[s][p] = *reinterpret_cast<const u4 *>(tile + plane_off8<TM_TILE, 256, true>(p, 16 * (s % NRB) + m, 4 * (s / NRB) + q));
+            x[s][p] = *reinterpret_cast<const u4 *>(tile + plane_off8<ROWS, 256, true>(p, 16 * (s % NRB) + m, 4 * (s / NRB) + q));
     static_for<0, NS>([&](auto S) {
         constexpr int s = decltype(S)::value;
         if constexpr (s + PF < NS) {
             constexpr int sn = s + PF;
 #pragma unroll
             for (int p = 0; p < SP::NP; ++p)
-                x[sn % NB][p] = *reinterpret_cast<const u4 *>(tile + plane_off8<TM_TILE, 256, true>(p, 16 * (sn % NRB) + m, 4 * (sn / NRB) + q));
+                x[sn % NB][p] = *reinterpret_cast<const u4 *>(tile + plane_off8<ROWS, 256, true>(p, 16 * (sn % NRB) + m, 4 * (sn / NRB) + q));
         }
         __builtin_amdgcn_sched_barrier(0);
         SP::mma(w[0][s / NRB].p, x[s % NB], acc[s % NRB][0], lo[s % NRB][0]);
