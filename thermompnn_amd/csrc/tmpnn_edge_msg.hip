@@ -38,6 +38,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
     const unsigned ucol = (unsigned)ncol;
     const unsigned eoff = (unsigned)(m * TM_H + ncol);
     const unsigned soff = (unsigned)((6 * wv + (lane >> 5)) * TM_H + 4 * c32);
+    const unsigned foff = (unsigned)(wv * 8192 + lane * 16);              // this lane's 16 bytes inside a fragment image (+ 2048 step + 1024 plane)
 
     for (int i = tm_bid(); i < a.T; i += tm_nblk()) {
         // ---- edge update of this tile (enc_edge8_rp_kernel) ------------------------------------------
@@ -50,6 +51,15 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
         //  prefetch in flight: 18.4 us per launch against 15.8.)
         WFragS<SP> fa[1][4], fb[1][4];
         f4 bias2;
+        // round 6: the fragment a GEMM phase later needs is requested piece by piece behind the MFMA steps of the GEMM that runs on the OTHER
+        // register set (eight global_loads in a row cost the wavefront ~85 cycles of issue each); the images exist for every f16x2 handle
+        auto ride_into = [&](const char *img, WFragS<SP> (&dst)[1][4], auto S) {
+            constexpr int s = decltype(S)::value;
+            static_for<0, 8>([&](auto K) {                                       // (scalar image base + ONE 32-bit lane offset for every image)
+                constexpr int k = decltype(K)::value;
+                if constexpr ((k * 12) / 8 == s) dst[0][k >> 1].p[k & 1] = *reinterpret_cast<const u4 *>(img + (foff + 2048u * (k >> 1) + 1024u * (k & 1)));
+            });
+        };
         {
             load_wfrag_auto<SP>(a.img11, a.W11e, 384, wv, lane, fa[0]);
             load_wfrag_auto<SP>(a.img12, a.W12, TM_H, wv, lane, fb[0]);
@@ -84,8 +94,6 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = gai + gcj[rb];
             mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tE, fa, acc, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            load_wfrag_auto<SP>(a.img13, a.W13, TM_H, wv, lane, fa[0]);          // W11 is done with: W13 for GEMM 3
             {
                 f4 g[3];
 #pragma unroll
@@ -97,9 +105,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             __syncthreads();
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b12;
-            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tX, fb, acc, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            load_wfrag_auto<SP, true>(b.imgp1, b.W1e, b.ld1, wv, lane, fb[0]);   // W12 is done with: the message pass's W1 (its K order: perm_c4)
+            mma_tile_split_ride<SP, 4, 3, TM_EDGE_PF>(tX, fb, acc, lane, [&](auto S) { ride_into(a.img13, fa, S); });   // W11 is done with: W13 for GEMM 3
             {
                 f4 g[3];
 #pragma unroll
@@ -111,9 +117,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             __syncthreads();
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = b13;
-            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_EDGE_PF>(tY, fa, acc, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            load_wfrag_auto<SP, true>(b.imgp2, b.W2, TM_H, wv, lane, fa[0]);     // W13 is done with: the message pass's W2
+            mma_tile_split_ride<SP, 4, 3, TM_EDGE_PF>(tY, fa, acc, lane, [&](auto S) { ride_into(b.imgp1, fb, S); });   // W12 is done with: the message pass's W1 (its K order: perm_c4)
             bias2 = ld4(b.b2 + ncol);
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void edge_msg_fused_kernel(EdgeArgsB a, Msg
             f4 acc[3][1];
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[rb][0] = DEC ? gj[rb] : g0 + gj[rb];
-            mma_tile_split<SP, 4, 1, 3, TM_TILE, 256, 4, 0, true, TM_MSG_PF>(tE, fb, acc, lane);
+            mma_tile_split_ride<SP, 4, 3, TM_MSG_PF>(tE, fb, acc, lane, [&](auto S) { ride_into(b.imgp2, fa, S); });     // W13 is done with: the message pass's W2
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
                 f4 v = acc[rb][0];

@@ -99,6 +99,24 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
         }
     };
     const int first_proj = has0 ? 9 : 11;                       // first projection unit, if any
+    // GEMM of the unit in `wf` with the NEXT unit's fragment requested meanwhile (u_next < 0: none). With images (round 6) its eight
+    // requests ride one by one behind the GEMM's MFMA steps instead of standing in a row in front of it (~85 cycles of issue each).
+    auto gemm = [&](const char *plane, f4 (&ac)[NRB][1], int u_next) {
+        if constexpr (IMG) {
+            const char *pn = a.img[u_next < 0 ? 0 : u_next] + (size_t)wv * 8192 + lane * 16;     // (none: unit 0 again, unconditional requests)
+            constexpr int NS = 4 * NRB;
+            mma_tile_split_ride<SP, 4, NRB, TM_NODE_PF, ROWS>(plane, wf, ac, lane, [&](auto S) {
+                constexpr int s = decltype(S)::value;
+                static_for<0, 8>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    if constexpr ((k * NS) / 8 == s) raw[k] = *reinterpret_cast<const f4 *>(pn + 2048 * (k >> 1) + 1024 * (k & 1));
+                });
+            });
+        } else {
+            if (u_next >= 0) issue(u_next);
+            mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(plane, wf, ac, lane);
+        }
+    };
 
     int tile = tm_bid();
     if (tile >= n_tiles) return;
@@ -192,10 +210,9 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
 
         f4 acc[NRB][1];
         split_raw();
-        issue(1);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = f4{0.f, 0.f, 0.f, 0.f};
-        mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pA, wf, acc, lane);
+        gemm(pA, acc, 1);
         {
             const f4 b3 = ld4(s_par + P_B3 + ncol);
 #pragma unroll
@@ -232,22 +249,18 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {           // FFN hidden 512 in four 128-wide chunks
             split_raw();                        // W_in chunk c
-            issue(2 + 2 * c);
             {
                 const f4 b = ld4(s_par + P_BIN + 128 * c + ncol);
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
             }
-            mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pB, wf, acc, lane);
+            gemm(pB, acc, 2 + 2 * c);
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) store_split<SP, ROWS>(pA, 16 * rb + m, c4, gelu4(acc[rb][0]));
             __syncthreads();
             mark();
             split_raw();                        // W_out chunk c
-            if (c < 3) issue(3 + 2 * c);
-            else if (has0 || has1) issue(first_proj);
-            else if (tile + (int)tm_nblk() < n_tiles) issue(0);
-            mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pA, wf, out, lane);
+            gemm(pA, out, c < 3 ? 3 + 2 * c : (has0 || has1) ? first_proj : tile + (int)tm_nblk() < n_tiles ? 0 : -1);
             __syncthreads();
             mark();
         }
@@ -279,15 +292,12 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
             for (int half = 0; half < 2; ++half) {
                 split_raw();
                 // next unit: the C half, the other projection, or W3 of this workgroup's next tile
-                if (!half) issue(10 + 2 * k);
-                else if (k == 0 && has1) issue(11);
-                else if (tile + (int)tm_nblk() < n_tiles) issue(0);
                 {
                     const f4 b = half ? f4{0.f, 0.f, 0.f, 0.f} : ld4(s_par + P_BA + 128 * k + ncol);
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = b;
                 }
-                mma_tile_split<SP, 4, 1, NRB, ROWS, 256, 4, 0, true, TM_NODE_PF>(pB, wf, acc, lane);
+                gemm(pB, acc, !half ? 10 + 2 * k : (k == 0 && has1) ? 11 : tile + (int)tm_nblk() < n_tiles ? 0 : -1);
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     const int row = r0 + 16 * rb + m;
