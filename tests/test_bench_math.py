@@ -95,6 +95,26 @@ def test_committed_isa_counts_belong_to_the_committed_kernel_sources():
         assert 0.2 < im["frac_overlap"] < im["frac_serial"] < 1.0
 
 
+def test_no_shipped_per_edge_or_node_kernel_spills_to_scratch():
+    """Round 6: a per-edge kernel that spills even 20 bytes reloads them inside its tile loop, and a scratch reload's vmcnt wait drains every
+    prefetch in flight (the fused edge + message kernel did, for one build). The ISA record of the committed sources (tools/isa_counts.py,
+    made without a GPU) must show no scratch for the f16x2 / bf16x3 per-edge, node, head and featurizer kernels."""
+    import glob
+    import json
+    import bench
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_isa_counts.json")), reverse=True)
+    d = next(x for x in (json.load(open(f)) for f in files) if x.get("source_stamp") == bench.kernel_source_stamp())
+    hot = ("enc_edge8_rp_kernel", "msg8_wave_kernel", "msg8_rp_kernel", "edge_msg_fused_kernel", "node_update8_split_kernel", "node_update8_deep_kernel",
+           "head8_split_kernel", "featurize_split_kernel")
+    seen = set()
+    for name, e in d["kernels"].items():
+        for h in hot:
+            if h in name:
+                seen.add(h)
+                assert int(e.get("scratch_bytes") or 0) == 0, f"{name} spills {e['scratch_bytes']} bytes of scratch"
+    assert seen == set(hot), sorted(set(hot) - seen)
+
+
 def test_tracked_round_evidence_is_not_empty_and_belongs_to_these_kernels():
     """`profiles/r04_parity_worst_errors.json` was committed as `{}` while DESIGN quoted it. Every tracked JSON of the
     newest round under profiles/ must hold something, the parity record must be the GPU suite's (>= 150 entries), and the files that

@@ -172,6 +172,21 @@ def test_sharded_scan_gloo(world):
     assert [sorted(ids) for _, _, ids in sorted(results)] == shards
 
 
+def test_csv_shard_bounds_and_memory_budget(monkeypatch):
+    """the memory form of the sharded CSV writer is bounded by the host's memory (a third of MemAvailable per local rank, at
+    most 16 GiB, never below 64 MiB), and the text bound counts the bytes the native writer emits: UTF-8, doubled quotes, two enclosing
+    quotes — a name of quotes or non-ASCII letters must not overflow a buffer sized by its character count."""
+    from thermompnn_amd import dist as tdist
+    one = tdist.default_memory_budget(1)
+    assert 64 << 20 <= one <= 16 << 30
+    assert tdist.default_memory_budget(8) <= one
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert tdist.default_memory_budget() == tdist.default_memory_budget(4)
+    assert tdist._csv_field_bytes("abc") == 5
+    assert tdist._csv_field_bytes('a"b"') == 4 + 2 + 2
+    assert tdist._csv_field_bytes("prot\u00e9ine") == len("prot\u00e9ine".encode()) + 2 == 11
+
+
 def test_partition_is_balanced_and_deterministic():
     lengths = [int(x) for x in np.random.default_rng(1).integers(64, 513, size=1024)]   # BASELINE config 3
     for world in (1, 2, 4, 8):
@@ -236,21 +251,23 @@ def _csv_worker(rank, world, port, paths, out, pick, cen, q, max_part_bytes=None
 @pytest.mark.parametrize("n_files,pick,cen,in_memory,world,shared_fs", [
     (7, False, True, True, 2, None), (7, True, False, True, 2, None), (1, False, False, True, 2, None), (5, False, False, False, 2, None),
     (5, False, True, True, 8, None), (5, True, False, True, 8, None), (11, False, False, False, 8, None), (7, False, True, True, 4, None),
-    (7, False, True, True, 2, False), (5, True, False, True, 4, False)])
+    (7, False, True, True, 2, False), (5, True, False, True, 4, False), (-5, True, False, True, 2, None)])
 def test_sharded_csv_is_byte_identical_to_the_one_writer_file(tmp_path, n_files, pick, cen, in_memory, world, shared_fs):
     """dist.scan_files_to_csv on 2 / 4 / 8 gloo ranks (a stand-in pipeline on CPU): the one output file equals what ONE writer makes
     of the same tables in file order — running indices, --pick_best's dupe_detector column, neighbour counts — including the cases
     where ranks' shards are empty (one file on two ranks; five files on eight ranks: three empty shards). A rank keeps its text in
     memory until the byte counts are exchanged; ``in_memory=False`` forces the part-file form used for very large shards (gone
     afterwards). ``shared_fs=False``: the gather-to-rank-0 writer that replaces the sharded one on a file system the ranks do not
-    share (None probes: the temporary directory is shared, so the sharded writer runs)."""
+    share (None probes: the temporary directory is shared, so the sharded writer runs). ``n_files < 0``: file names full of quotes and
+    non-ASCII letters (twice per row with ``--pick_best``): the text bound of the memory form counts encoded, quoted bytes."""
     import shutil
     from conftest import GOLDEN
     from thermompnn_amd import native_csv, native_pdb
     src = [os.path.join(GOLDEN, "2OCJ.pdb"), os.path.join(GOLDEN, "2OCJ_gap_chainA.pdb")]
     paths = []
+    odd_names, n_files = n_files < 0, abs(n_files)
     for k in range(n_files):
-        dst = str(tmp_path / f"prot{k}.pdb")
+        dst = str(tmp_path / (f'x"q""\u00e9\u00fc\u4e2d{k}.pdb' if odd_names else f"prot{k}.pdb"))
         shutil.copy(src[k % 2], dst)
         paths.append(dst)
     out = str(tmp_path / "sharded.csv")
@@ -269,7 +286,7 @@ def test_sharded_csv_is_byte_identical_to_the_one_writer_file(tmp_path, n_files,
     tabs = [_seq_table(p["seq"], cen) for p in prots]
     off = np.concatenate([[0], np.cumsum([len(p["seq"]) for p in prots])]).astype(np.int32)
     with native_csv.CsvWriter(str(tmp_path / "one.csv")) as w:
-        w.write_ssm(np.concatenate([t for t, _ in tabs]), off, [p["seq"] for p in prots], [f"prot{k}".strip(".pdb") for k in range(n_files)],
+        w.write_ssm(np.concatenate([t for t, _ in tabs]), off, [p["seq"] for p in prots], [os.path.basename(x)[:-4].strip(".pdb") for x in paths],
                     neighbors=np.concatenate([nb for _, nb in tabs]) if cen else None, dataset="my set", pick_best=pick,
                     include_cys=not pick, n_threads=2)
     want = (tmp_path / "one.csv").read_bytes()

@@ -143,7 +143,8 @@ def main():
             meta = {}
             for m in re.finditer(r"\.amdhsa_kernel\s+(\S+)(.*?)\.end_amdhsa_kernel", asm, flags=re.S):
                 g = lambda key: (re.search(r"\.amdhsa_" + key + r"\s+(\d+)", m.group(2)) or [None, None])[1]
-                meta[m.group(1)] = {"next_free_vgpr": g("next_free_vgpr"), "accum_offset": g("accum_offset"), "lds_bytes": g("group_segment_fixed_size")}
+                meta[m.group(1)] = {"next_free_vgpr": g("next_free_vgpr"), "accum_offset": g("accum_offset"), "lds_bytes": g("group_segment_fixed_size"),
+                                    "scratch_bytes": g("private_segment_fixed_size")}
             for sym, body in ks.items():
                 loop = main_loop(body)
                 entry = {"file": src, "whole_kernel": count(body), **meta.get(sym, {})}
