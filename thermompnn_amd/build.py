@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libtmpnn.so")
 DEBUG_LIB = os.path.join(HERE, "libtmpnn_debug.so")
 SOURCES = ["tmpnn_api.hip", "tmpnn_graph.hip", "tmpnn_layers.hip", "tmpnn_head.hip", "tmpnn_split.hip", "tmpnn_edge.hip", "tmpnn_msg.hip",
            "tmpnn_edge_msg.hip", "tmpnn_edge_wave.hip", "tmpnn_node.hip", "tmpnn_pdb.cpp", "tmpnn_csv.cpp"]
-HEADERS = ["tmpnn_common.h", "tmpnn_split.h", "tmpnn_internal.h", os.path.join("..", "..", "include", "tmpnn.h"),
+HEADERS = ["tmpnn_common.h", "tmpnn_split.h", "tmpnn_internal.h", "tmpnn_head_body.h", os.path.join("..", "..", "include", "tmpnn.h"),
            os.path.join("..", "..", "include", "tmpnn_debug.h"), "tmpnn_host_guard.hpp"]
 # -mcode-object-version=5: tm_nblk() / tm_bdim() (tmpnn_common.h) read gridDim / blockDim at fixed offsets of the v5
 # implicit-argument block; pinned here and checked on the device by tmpnn_selftest.

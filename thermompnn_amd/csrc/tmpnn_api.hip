@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "tmpnn_internal.h"
+#include "tmpnn_head_body.h"
 #include "../../include/tmpnn_debug.h"
 
 // ---- errors ---------------------------------------------------------------------------------------
@@ -673,6 +674,7 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
     // node_update of every layer writes the projection the next message pass needs into ws.P — 18 launches per forward
     // (28 when every projection and the zero state are launches of their own)
     static const bool fuse_small = TM_DBG_FLAG("TMPNN_FUSE_SMALL", true);     // (A/B switch in the debug library only)
+    bool head_done = false;                                                   // the ddG head ran inside the last node update's launch
     const KnnInit kinit{hV[0], ws.P, w->enc[0].b1, status_opt};
     if (fuse_small && max_len <= 256 && featurize_fusable(w, T)) {             // one tile per workgroup: k-NN inside the featurizer launch
         const KnnFuse kf{mask, offsets, n_proteins, max_len, K, E_idx, D_nb, kinit};
@@ -705,8 +707,12 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
             const DecW &d = w->dec[l];
             if (l > 0) TRY(launch_msg(true, d.W1 + 128, 512, d.W2, d.b2, ws.P, hE, E_idx, mask, T, ws.Ssum, ws.cnt, st));
             const NodeProj next = dec_msg_proj(w, l < 2 ? l + 1 : 2, ws.P, S);
+            // last layer: its node update and the ddG head of the same 16 residues are ONE launch (node_head_fused_kernel, bit-identical)
+            HeadArgs ha;
+            const bool with_head = l == 2 && ddg && node_head_fusable(tm_matmul_mode(), T);
+            if (with_head) { ha = tm_head_args(w, hV[3], hV[2], S, T, ddg, nullptr, status_opt, E_idx); head_done = ha.img[0] != nullptr; }
             TRY(launch_node_update(d.W3, d.b3, d.norm1_w, d.norm1_b, d.Win, d.bin, d.Wout, d.bout, d.norm2_w, d.norm2_b, hV[l],
-                                   ws.Ssum, ws.cnt, mask, T, hV[l + 1], l < 2 ? &next : nullptr, nullptr, st));
+                                   ws.Ssum, ws.cnt, mask, T, hV[l + 1], l < 2 ? &next : nullptr, nullptr, st, with_head && head_done ? &ha : nullptr));
         }
     } else {
         for (int l = 0; l < 3; ++l) {
@@ -718,7 +724,7 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
             TRY(run_dec_layer(w, l, hV[l], hV[l + 1], hE, E_idx, S, mask, T, ws, true, l < 2 ? &next : nullptr, st));
         }
     }
-    if (ddg) TRY(launch_head(w, hV[3], hV[2], S, T, ddg, nullptr, status_opt, st, E_idx));
+    if (ddg && !head_done) TRY(launch_head(w, hV[3], hV[2], S, T, ddg, nullptr, status_opt, st, E_idx));
     if (log_probs_opt) TRY(launch_log_probs(w, hV[3], T, log_probs_opt, status_opt, st, ddg ? nullptr : E_idx));
     // hidden states only: neither of the kernels above has looked at the last decoder state (a poisoned value anywhere upstream
     // has reached it through its neighbours by now)

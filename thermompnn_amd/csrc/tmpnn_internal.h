@@ -102,17 +102,22 @@ struct NodeArgs {
     ProjSpec proj[2];       // proj[k].P == nullptr -> not requested
     const char *img[13];    // fragment images of the 13 GEMM units (W3, W_in/W_out chunk pairs, projections) or all null
 };
-int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st);
+struct HeadArgs;
+// head != nullptr (small launches, no projections requested): the ddG head of the same rows runs in the same launch (node_head_fused_kernel)
+int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st, const HeadArgs *head = nullptr);
+bool node_head_fusable(int mode, int64_t T);
 int launch_node_proj(const float *h, const NodeProj &np, int64_t T, hipStream_t st);
 int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
                        const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,
-                       float *h_out, const NodeProj *p0, const NodeProj *p1, hipStream_t st);
+                       float *h_out, const NodeProj *p0, const NodeProj *p1, hipStream_t st, const HeadArgs *head = nullptr);
 int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
 
 // tmpnn_head.hip
 int launch_head(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg,
                 float *z_opt, int32_t *status, hipStream_t st, const int32_t *maxlen_probe = nullptr);
+HeadArgs tm_head_args(const tmpnn_weights *w, const float *hA, const float *hB, const int32_t *S, int64_t T, float *ddg, float *z_opt,
+                      int32_t *status, const int32_t *maxlen_probe);
 int launch_log_probs(const tmpnn_weights *w, const float *h, int64_t T, float *out, int32_t *status, hipStream_t st,
                      const int32_t *maxlen_probe = nullptr);
 int launch_seq_embed(const tmpnn_weights *w, const int32_t *S, int64_t T, float *hS, hipStream_t st);

@@ -6,6 +6,7 @@
 
 #include "tmpnn_split.h"
 #include "tmpnn_internal.h"
+#include "tmpnn_head_body.h"
 
 // ------------------------------------------------------------------------------------------------
 // node_update, 8-wavefront f16x2 form (default): one workgroup per CU, up to 64 residues per tile, 16 output columns per
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void node_update8_split_kernel(NodeArgs a, 
 // Arithmetic and its order are those of node_update8_split_kernel (bit-identical results).
 // ------------------------------------------------------------------------------------------------
 template <int NPROJ, int D, bool PROF = false>
-__global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsigned long long *prof = nullptr) {
+__device__ __forceinline__ void node_deep_body(const NodeArgs &a, unsigned long long *prof) {
     using SP = SplitH2;
     int n_mark = 0;
     auto mark = [&]() {                 // TMPNN_NODE_PROF=1: cycle stamps of thread 0 of workgroup 0 at every stage boundary
@@ -481,7 +482,24 @@ __global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsi
     }
 }
 
-int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
+template <int NPROJ, int D, bool PROF = false>
+__global__ __launch_bounds__(512) void node_update8_deep_kernel(NodeArgs a, unsigned long long *prof = nullptr) {
+    node_deep_body<NPROJ, D, PROF>(a, prof);
+}
+
+// Small launches, last decoder layer (round 6): the node update of a workgroup's 16 residues and the ddG head of the SAME 16 residues in one
+// launch — the head needs the new state of exactly these rows, the previous decoder state and the sequence embedding: no grid-wide
+// dependency, and a launch costs 2.5 us of dispatch + 2-3 us of start-up whatever it does (tools/gap_probe.py). The new state goes to
+// global memory as before (h_out is an output of the forward); the barrier between the two bodies makes the workgroup's own rows
+// visible to all of its threads (stores complete at L2 before it, the rows were never in this CU's L1). Bodies unchanged: bit-identical
+// to the two launches (tools/dbg_fused.py).
+__global__ __launch_bounds__(512) void node_head_fused_kernel(NodeArgs a, HeadArgs h) {
+    node_deep_body<0, TM_NODE_DEEP_D>(a, nullptr);
+    __syncthreads();
+    head8_body<SplitH2, 1, true>(h);
+}
+
+int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st, const HeadArgs *head) {
     // tile height (16..64 rows, one workgroup per CU) for load balance: every tile streams the same 0.8 MB of weights,
     // worth about `wcost` rows of (cheaper) matrix time
     const int64_t slots = tm_num_cus();
@@ -524,6 +542,10 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
             return tm_check_launch("node_update8_deep");
         }
 #endif
+        if (np == 0 && head && head->img[0]) {                  // + the ddG head of the same rows (the caller checked node_head_fusable)
+            node_head_fused_kernel<<<g16, 512, 0, st>>>(b, *head);
+            return tm_check_launch("node_head_fused");
+        }
         if (np == 0) node_update8_deep_kernel<0, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
         else if (np == 1) node_update8_deep_kernel<1, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
         else node_update8_deep_kernel<2, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
@@ -555,4 +577,10 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st) {
     }
 #undef TM_NODE8
     return tm_check_launch("node_update8_split");
+}
+
+// the fused launch exists for f16x2 handles with fragment images, when every workgroup has one 16-row tile (the deep form's condition)
+bool node_head_fusable(int mode, int64_t T) {
+    static const int deep = TM_DBG_INT("TMPNN_NODE_DEEP", 1);
+    return mode == TM_MM_F16X2 && deep && T > 0 && (T + 15) / 16 <= (int64_t)tm_num_cus();
 }
