@@ -894,15 +894,15 @@ def test_profile_hook_records_one_kernel_when_asked(engine):
     from thermompnn_amd import _lib
     lib = _lib.load()
     eng = engine
-    # a launch with at most one tile per workgroup computes the k-NN rows inside the featurizer launch and fuses the edge update
-    # with the next message pass: 14 launches, other names
+    # a launch with at most one tile per workgroup computes the k-NN rows inside the featurizer launch, fuses the edge update
+    # with the next message pass and (round 6) the last node update with the ddG head: 13 launches, other names
     small = bench.build_batch(2, 64, 0, torch.device("cuda:0"))
     lib.tmpnn_profile_enable(1)
     eng.ssm_forward(small["X"], small["S"], small["mask"], small["ridx"], small["cenc"], small["offsets"], max_len=64)
     fused = bench.fetch_profile(lib)
     lib.tmpnn_profile_enable(0)
     assert fused["edge_msg_fused"][1] == 3 and fused["enc_msg"][1] == 1 and fused["dec_msg"][1] == 2 and "enc_edge" not in fused
-    assert fused["node_update"][1] == 6 and "knn" not in fused and sum(int(v[1]) for v in fused.values()) == 14
+    assert fused["node_update"][1] == 6 and "knn" not in fused and "head" not in fused and sum(int(v[1]) for v in fused.values()) == 13
     b = bench.build_batch(8, 64, 0, torch.device("cuda:0"))           # 512 tiles > #CUs: the 18-launch form
     fwd = lambda: eng.ssm_forward(b["X"], b["S"], b["mask"], b["ridx"], b["cenc"], b["offsets"], max_len=64)
     fwd()

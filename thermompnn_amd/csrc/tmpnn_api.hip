@@ -710,9 +710,10 @@ extern "C" int tmpnn_ssm_forward(const tmpnn_weights_t *w, const float *X, const
             // last layer: its node update and the ddG head of the same 16 residues are ONE launch (node_head_fused_kernel, bit-identical)
             HeadArgs ha;
             const bool with_head = l == 2 && ddg && node_head_fusable(tm_matmul_mode(), T);
-            if (with_head) { ha = tm_head_args(w, hV[3], hV[2], S, T, ddg, nullptr, status_opt, E_idx); head_done = ha.img[0] != nullptr; }
+            if (with_head) ha = tm_head_args(w, hV[3], hV[2], S, T, ddg, nullptr, status_opt, E_idx);
             TRY(launch_node_update(d.W3, d.b3, d.norm1_w, d.norm1_b, d.Win, d.bin, d.Wout, d.bout, d.norm2_w, d.norm2_b, hV[l],
-                                   ws.Ssum, ws.cnt, mask, T, hV[l + 1], l < 2 ? &next : nullptr, nullptr, st, with_head && head_done ? &ha : nullptr));
+                                   ws.Ssum, ws.cnt, mask, T, hV[l + 1], l < 2 ? &next : nullptr, nullptr, st, with_head ? &ha : nullptr,
+                                   with_head ? &head_done : nullptr));
         }
     } else {
         for (int l = 0; l < 3; ++l) {

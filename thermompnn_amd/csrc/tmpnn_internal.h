@@ -103,14 +103,16 @@ struct NodeArgs {
     const char *img[13];    // fragment images of the 13 GEMM units (W3, W_in/W_out chunk pairs, projections) or all null
 };
 struct HeadArgs;
-// head != nullptr (small launches, no projections requested): the ddG head of the same rows runs in the same launch (node_head_fused_kernel)
-int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st, const HeadArgs *head = nullptr);
+// head != nullptr (small launches, no projections requested): the ddG head of the same rows MAY run in the same launch (node_head_fused_kernel);
+// *head_ran says whether it did — the caller launches the head itself otherwise
+int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st, const HeadArgs *head = nullptr, bool *head_ran = nullptr);
 bool node_head_fusable(int mode, int64_t T);
 int launch_node_proj(const float *h, const NodeProj &np, int64_t T, hipStream_t st);
 int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
                        const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,
-                       float *h_out, const NodeProj *p0, const NodeProj *p1, hipStream_t st, const HeadArgs *head = nullptr);
+                       float *h_out, const NodeProj *p0, const NodeProj *p1, hipStream_t st, const HeadArgs *head = nullptr,
+                       bool *head_ran = nullptr);
 int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_idx, int64_t T, hipStream_t st);
 
 // tmpnn_head.hip

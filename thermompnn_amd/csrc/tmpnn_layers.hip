@@ -521,7 +521,8 @@ int launch_enc_edge(const EncW &e, const float *P, float *hE, const int32_t *E_i
 int launch_node_update(const float *W3, const float *b3, const float *n1w, const float *n1b, const float *Win,
                        const float *bin, const float *Wout, const float *bout, const float *n2w, const float *n2b,
                        const float *h_in, const float *Ssum, const float *cnt, const float *mask, int64_t T,
-                       float *h_out, const NodeProj *p0, const NodeProj *p1, hipStream_t st, const HeadArgs *head) {
+                       float *h_out, const NodeProj *p0, const NodeProj *p1, hipStream_t st, const HeadArgs *head, bool *head_ran) {
+    if (head_ran) *head_ran = false;
     NodeArgs a{W3, b3, n1w, n1b, Win, bin, Wout, bout, n2w, n2b, h_in, Ssum, cnt, mask, h_out, (int)T, {}};
     const NodeProj *ps[2] = {p0, p1};
     for (int k = 0; k < 2; ++k)
@@ -553,7 +554,7 @@ int launch_node_update(const float *W3, const float *b3, const float *n1w, const
     }
     static const bool split_ok = TM_DBG_FLAG("TMPNN_NODE_SPLIT", true);
     if (tm_matmul_mode() == TM_MM_F16X2 && split_ok) {
-        const int rc = launch_node_update_split(a, T, st, head);
+        const int rc = launch_node_update_split(a, T, st, head, head_ran);
         tm_prof_end(st);
         return rc;
     }

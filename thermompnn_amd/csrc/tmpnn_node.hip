@@ -499,7 +499,8 @@ __global__ __launch_bounds__(512) void node_head_fused_kernel(NodeArgs a, HeadAr
     head8_body<SplitH2, 1, true>(h);
 }
 
-int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st, const HeadArgs *head) {
+int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st, const HeadArgs *head, bool *head_ran) {
+    if (head_ran) *head_ran = false;
     // tile height (16..64 rows, one workgroup per CU) for load balance: every tile streams the same 0.8 MB of weights,
     // worth about `wcost` rows of (cheaper) matrix time
     const int64_t slots = tm_num_cus();
@@ -544,6 +545,7 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st, const
 #endif
         if (np == 0 && head && head->img[0]) {                  // + the ddG head of the same rows (the caller checked node_head_fusable)
             node_head_fused_kernel<<<g16, 512, 0, st>>>(b, *head);
+            if (head_ran) *head_ran = true;
             return tm_check_launch("node_head_fused");
         }
         if (np == 0) node_update8_deep_kernel<0, TM_NODE_DEEP_D><<<g16, 512, 0, st>>>(b);
@@ -582,5 +584,6 @@ int launch_node_update_split(const NodeArgs &a, int64_t T, hipStream_t st, const
 // the fused launch exists for f16x2 handles with fragment images, when every workgroup has one 16-row tile (the deep form's condition)
 bool node_head_fusable(int mode, int64_t T) {
     static const int deep = TM_DBG_INT("TMPNN_NODE_DEEP", 1);
-    return mode == TM_MM_F16X2 && deep && T > 0 && (T + 15) / 16 <= (int64_t)tm_num_cus();
+    static const bool split = TM_DBG_FLAG("TMPNN_NODE_SPLIT", true) && TM_DBG_FLAG("TMPNN_HEAD_SPLIT", true);   // (the debug library's fp32-form switches)
+    return mode == TM_MM_F16X2 && deep && split && T > 0 && (T + 15) / 16 <= (int64_t)tm_num_cus();
 }
