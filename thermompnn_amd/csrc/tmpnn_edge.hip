@@ -18,11 +18,14 @@
 // OFF32: see msg8_rp_kernel (32-bit gather offsets when the projection table is smaller than 4 GB).
 template <typename SP, bool PROF = false, bool OFF32 = false>
 __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsigned long long *prof = nullptr) {
-    unsigned long long t_last = 0;
-    auto mark = [&](int k) {           // TMPNN_EDGE_PROF=1: phase timing of thread 0 of workgroup 0
-        if (PROF && tm_bid() == 0 && tm_tid() == TM_PROF_TID) {
-            const unsigned long long t = __builtin_readcyclecounter();
-            if (k >= 0) prof[k] += t - t_last;
+    // TMPNN_EDGE_PROF=1 (debug library): phase timing of one wavefront of workgroup 0 in scalar registers (s_memtime + SALU adds, written out once
+    // behind the loop; round 6 — a timer that does a global read-modify-write per mark waits for every request in flight at every mark: +15 %)
+    unsigned t_last = 0, t_acc[11] = {};
+    auto mark = [&](int k) {
+        if constexpr (PROF) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned t = (unsigned)__builtin_readcyclecounter();
+            if (k >= 0) t_acc[k] += t - t_last;
             t_last = t;
         }
     };
@@ -214,6 +217,8 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         mark(10);
     }
     if (PROF && tm_bid() == 0 && tm_tid() == TM_PROF_TID) {               // shader cycles and 100 MHz ticks of the loop: the clock under THIS load
+#pragma unroll
+        for (int k = 0; k < 11; ++k) prof[k] = t_acc[k];
         prof[11] = __builtin_readcyclecounter() - c_begin;
         prof[12] = wall_clock64() - w_begin;
     }
