@@ -30,7 +30,6 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         }
     };
     constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
-    static_assert(TILEB >= TM_TILE * TM_H * 4, "the fp32 LayerNorm tile is aliased on the x planes");
     __shared__ __attribute__((aligned(16))) char tE[TILEB];
     __shared__ __attribute__((aligned(16))) char tX[TILEB];              // x planes; later the fp32 LayerNorm input
     // GEMM 2's output planes live where the e planes were: GEMM 1 was their last reader (every wavefront is past the barrier behind
@@ -38,12 +37,15 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
     // 53 KB of LDS, every LDS offset below 64 KB (an offset above costs an address VGPR + a v_or each: 10 VALU per tile).
     // bf16x3 (round 6): its three planes re-join exactly, so the e planes ARE the residual (no fp32 copy of the tile in registers) and GEMM 2's
     // output gets a tile of its own (3 x 36 KB of LDS); the per-column parameters come from LDS. 48 weight VGPRs per matrix leave no room otherwise.
-    __shared__ __attribute__((aligned(16))) char tY3[SP::EXACT ? TILEB : 16];
-    char *const tY = SP::EXACT ? tY3 : tE;
+    // Round 6, THREE barriers per tile instead of four: GEMM 2's output planes and the fp32 LayerNorm tile have tiles of their own (98 KB of LDS
+    // in f16x2, 141 KB in bf16x3; until then tY aliased the e planes and tO the x planes), the next tile's e planes are written in the residual
+    // phase (GEMM 1 read the old ones two barriers ago), so nothing separates a tile's LayerNorm / store phase from the next tile's GEMM 1 and
+    // GELU 1: the older wavefront of a SIMD runs ahead into the matrix phase while the younger finishes its rows, instead of waiting for it.
+    __shared__ __attribute__((aligned(16))) char tY[TILEB];
+    __shared__ __attribute__((aligned(16))) float tO[TM_TILE * TM_H];
     __shared__ __attribute__((aligned(16))) float s_par[SP::EXACT ? 4 : 1][TM_H];
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT_LD];
     __shared__ int s_idx[2][TM_TILE];
-    float *tO = reinterpret_cast<float *>(tX);
     const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
 
     WFragS<SP> w11[1][4], w12[1][4], w13[1][4];
@@ -180,16 +182,16 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
 #else
             row_stats_partial16(v, &s_stat[16 * rb + m][2 * wv], q);
 #endif
-        }
-        mark(7);
-        __syncthreads();                                                     // tE free, tO + stats complete
-        mark(8);
-
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            store_split<SP>(tE, 16 * rb + m, c4, e_nxt[rb]);
+            store_split<SP>(tE, 16 * rb + m, c4, e_nxt[rb]);                 // the next tile's e planes (this thread's own slot: the residual above read it)
             e_cur[rb] = e_nxt[rb];
         }
+        bool okr[3];                                                         // rows of this thread's LayerNorm phase that have a neighbour (s_idx[cur] is
+#pragma unroll                                                               //  rewritten by the next tile's GELU-1 phase, which no barrier separates from it)
+        for (int it = 0; it < 3; ++it) okr[it] = s_idx[cur][6 * wv + 2 * it + (lane >> 5)] >= 0;
+        mark(7);
+        __syncthreads();                                                     // tO + stats + the next e planes complete
+        mark(8);
+
         touch(gai);                                    // the next tile's gathers have long arrived: take their vmcnt wait
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) touch(gcj[rb]); // here, in front of the stores below (see touch())
@@ -209,12 +211,11 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
             const f2 y01 = __builtin_elementwise_fma(f2{x4.x, x4.y}, s01, t01), y23 = __builtin_elementwise_fma(f2{x4.z, x4.w}, s23, t23);
             const f4 y = f4{y01.x, y01.y, y23.x, y23.y};
             // rows without a neighbour keep the zeros the featurizer wrote: store zeros again (no divergent branch)
-            st4(tile_g + (soff + 2 * it * TM_H), s_idx[cur][row] >= 0 ? y : f4{0.f, 0.f, 0.f, 0.f});
+            st4(tile_g + (soff + 2 * it * TM_H), okr[it] ? y : f4{0.f, 0.f, 0.f, 0.f});
         }
         cur ^= 1;
         mark(9);
-        __syncthreads();
-        mark(10);
+        mark(10);                                                            // (no barrier here any more)
     }
     if (PROF && tm_bid() == 0 && tm_tid() == TM_PROF_TID) {               // shader cycles and 100 MHz ticks of the loop: the clock under THIS load
 #pragma unroll
