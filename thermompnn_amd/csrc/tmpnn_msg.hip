@@ -268,7 +268,10 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
     // once behind the loop — a timer that does a global read-modify-write per mark waits for every request in flight at every mark)
     unsigned t_last = 0, t_acc[8] = {};
     auto mark = [&](int k) {
-        if constexpr (PROF) {
+#ifndef TM_MSG_PROF_NOMARKS
+#define TM_MSG_PROF_NOMARKS 0                               // 1: only the loop totals of the wavefronts, the code between them as shipped
+#endif
+        if constexpr (PROF && !TM_MSG_PROF_NOMARKS) {
             __builtin_amdgcn_sched_barrier(0);              // (s_memtime is no scheduling barrier by itself: the phases would smear)
             const unsigned t = (unsigned)__builtin_readcyclecounter();
             if (k >= 0) t_acc[k] += t - t_last;
@@ -289,12 +292,28 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
     float *g0s = s_g0[wv];
 
     const TileRange tr = xcd_tile_range(a.T);
-    const int istep = 8 * tr.step;
+    // Residues of this workgroup: k = 0 .. n_wg - 1 <-> i = tr.begin + k tr.step; SIMD s = wavefronts s and s + 4 serves k = s + 4 t,
+    // t < m. Round 6: the two do NOT take m / 2 each. They do not share the SIMD evenly — the first-dispatched one (0..3) gets the matrix
+    // and vector slots it asks for at 29-30 k cycles a residue whatever its partner does, the partner (4..7) the rest: 60 k a residue beside
+    // it, 22 k alone. With equal shares wavefronts 0..3 were through after 234 k cycles and 4..7 after 334 k, alone for the last 30 % of
+    // the launch; with 11 of 16 against 5 both end at 313-316 k (TMPNN_MSG_PROF, "wave loops"; docs/NOTEBOOK.md 10.3f). An LDS ticket
+    // counter (every wavefront draws its next residue) ended as level in workgroup 0 but was 3 % slower over the launch than 11 : 5 — its
+    // granule is a residue of the slow wavefront, 60 k cycles. Any wavefront computes the same bits for a residue.
+#ifndef TM_MSG_WAVE_OLD_16TH
+#define TM_MSG_WAVE_OLD_16TH 11      // sixteenths of a SIMD's residues that its first-dispatched wavefront takes
+#endif
+    const int n_wg = tr.begin < tr.end ? (tr.end - tr.begin + tr.step - 1) / tr.step : 0;
+    const int wvs = tm_wave(tid), simd = wvs & 3;
+    const int m_simd = (n_wg - simd + 3) / 4;                     // residues of this SIMD (n_wg >= 0)
+    const int n_old = (m_simd * TM_MSG_WAVE_OLD_16TH + 8) / 16;
+    const int t0 = wvs < 4 ? 0 : n_old, nt = wvs < 4 ? n_old : m_simd - n_old;      // this wavefront: t = t0 .. t0 + nt - 1
+    auto res_at = [&](int t) { return __builtin_amdgcn_readfirstlane(tr.begin + (simd + 4 * (t0 + t)) * tr.step); };
+    int t_res = 0;
     // (the eight wavefronts of a workgroup are tr.step = 32 residues apart; giving them eight CONSECUTIVE residues, whose neighbour lists
     //  overlap, so that their gathers meet in the CU's L1 was measured in round 6: nil — 0.4182 / 0.4193 / 0.4175 against 0.4189 / 0.4194 /
     //  0.4186 of the featurizer's time in the same run)
-    int i = tr.begin + wv * tr.step;
-    if (i >= tr.end) return;
+    if (nt <= 0) return;
+    int i = res_at(0);
     const unsigned uq = 4u * (unsigned)q;
     const unsigned eoff = (unsigned)(n * TM_H) + uq;           // this lane's offset inside a 16-row block of e
 
@@ -355,7 +374,8 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
         for (int cb = 0; cb < 8; ++cb) sum[cb] = f4{0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // g0s is read back by this wavefront only (LDS is in order per wavefront)
         __builtin_amdgcn_wave_barrier();
-        const bool more = i + istep < tr.end;                   // this wavefront has another residue
+        const bool more = t_res + 1 < nt;                       // this wavefront has another residue
+        const int inx = more ? res_at(t_res + 1) : i;
 #pragma unroll 1
         for (int b = 0; b < 3; ++b) {                           // its three 16-row blocks: the loop tools/isa_counts.py counts
             // ---- the block's operands (requested one block ago)
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
             // copies around the loop — 64 v_mov_b64 per block in the first build of this kernel
             const bool last_b = b == 2;
             const bool has1 = !last_b || more;
-            const int i1 = has1 ? (last_b ? i + istep : i) : i, b1 = has1 ? (last_b ? 0 : b + 1) : b;
+            const int i1 = has1 ? (last_b ? inx : i) : i, b1 = has1 ? (last_b ? 0 : b + 1) : b;
             const BlockAddr ad1 = block_addr(i1, b1, has1 ? j_nxt : j_cur);
             // ---- the chain; the 16 request pieces ride behind the MFMA groups of GEMM 1
             mark(1);
@@ -388,8 +408,8 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
             if (last_b) issue_self(i1);
             {
                 const bool last_b1 = b1 == 2;
-                const int i2 = last_b1 ? i1 + istep : i1, b2 = last_b1 ? 0 : b1 + 1;
-                const bool has2 = has1 && i2 < tr.end;
+                const int i2 = last_b1 ? inx : i1, b2 = last_b1 ? 0 : b1 + 1;          // (b1 == 2 only when the next block is of THIS residue)
+                const bool has2 = has1 && (!last_b1 || more);
                 j_cur = j_nxt;
                 j_nxt = idx_of(has2 ? i2 : i1, has2 ? b2 : b1);
             }
@@ -442,7 +462,8 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
         if (lane == 15) a.cnt[i] = cnt;
         mark(6);
         if (!more) break;
-        i += istep;
+        ++t_res;
+        i = inx;
     }
     if (PROF && tm_bid() == 0 && tm_tid() == (TM_PROF_TID & ~63)) {       // shader cycles and 100 MHz ticks of the loop: the clock under THIS load
 #pragma unroll
@@ -450,6 +471,8 @@ __global__ __launch_bounds__(512, 2) void msg8_wave_kernel(MsgArgsB a, unsigned 
         prof[8] = __builtin_readcyclecounter() - c_begin;
         prof[9] = wall_clock64() - w_begin;
     }
+    if (PROF && (tm_bid() == 0 || tm_bid() == (int)gridDim.x - 1) && (tm_tid() & 63) == 0)                // every wavefront's loop, first and last workgroup
+        prof[(tm_bid() == 0 ? 16 : 24) + (tm_tid() >> 6)] = __builtin_readcyclecounter() - c_begin;
 }
 
 int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float *W2, const float *b2, const float *P,
@@ -475,13 +498,15 @@ int launch_msg_split(int mode, bool dec, const float *W1e, int ld1, const float 
         static const bool wprof = TM_DBG_FLAG("TMPNN_MSG_PROF", false);
         if (wprof && dec) {                          // debug build: phase timing of one wavefront of workgroup 0 (synchronises!)
             static unsigned long long *d_prof = nullptr;
-            if (!d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(unsigned long long));
-            (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+            if (!d_prof) (void)hipMalloc(&d_prof, 32 * sizeof(unsigned long long));
+            (void)hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), st);
             msg8_wave_kernel<true, false, true><<<(int)cap, 512, 0, st>>>(a, d_prof);
-            unsigned long long h[16];
+            unsigned long long h[32];
             (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
             fprintf(stderr, "dec_msg wave phases (cycles, one wavefront of wg 0, all its blocks): operands %llu requests %llu gemm1 %llu gelu+split %llu gemm2 %llu gelu+mask %llu ksum+store %llu; loop %llu cycles in %llu ticks of 100 MHz = %.3f GHz\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[9] ? h[8] / (h[9] * 10.0) : 0.0);
+            fprintf(stderr, "dec_msg wave loops (cycles, the eight wavefronts of wg 0): %llu %llu %llu %llu | %llu %llu %llu %llu; of the last wg: %llu %llu %llu %llu | %llu %llu %llu %llu\n",
+                    h[16], h[17], h[18], h[19], h[20], h[21], h[22], h[23], h[24], h[25], h[26], h[27], h[28], h[29], h[30], h[31]);
         } else
 #endif
         if (off32) {
