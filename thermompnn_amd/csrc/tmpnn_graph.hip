@@ -592,14 +592,25 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
     constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
     static_assert(SP::NP * PLB >= TILEB, "the GEMM-2 planes are aliased on the RBF planes");
     __shared__ __attribute__((aligned(16))) char rbf[SP::NP * PLB];
+#ifndef TM_FEAT_DIRECT_STORE
+#define TM_FEAT_DIRECT_STORE 1
+#endif
+#if TM_FEAT_DIRECT_STORE
+    __shared__ __attribute__((aligned(16))) char s_tA[TILEB];           // GEMM 2's operand planes: their own tile, not the RBF planes
+#else
     __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];   // fp32 output tile
+#endif
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT8_LD];
     __shared__ float s_atoms[TM_TILE][16];
     __shared__ float s_self[16];
     __shared__ float s_dist[TM_TILE][28];
     __shared__ int s_ix[2][2][TM_TILE];                      // [buffer][neighbour index | positional index][neighbour]: ONE array, one lane base
     __shared__ __attribute__((aligned(16))) float s_const[3][TM_H];   // W_e bias, LayerNorm gain / bias: read where used, not held (12 VGPRs)
+#if TM_FEAT_DIRECT_STORE
+    char *tAp = s_tA;
+#else
     char *tAp = rbf;
+#endif
     const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
     const int c32 = lane & 31;
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
@@ -904,6 +915,17 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = be;
         mma_tile_split<SP, 4, 1>(tAp, we, acc, lane);           // W_e (:1229)
+#if TM_FEAT_DIRECT_STORE
+        // round 6: h_E rows leave from the accumulators — a wavefront's store covers 16 rows x 64 B (its 16 columns) — instead of crossing
+        // LDS into full 512-byte rows: one barrier and one LDS round trip per tile less; the operand planes of GEMM 2 have the tile the
+        // fp32 rows had, so the next tile's Gaussians (into the RBF planes, last read two barriers ago) need no barrier behind GEMM 2
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int row = 16 * rb + m;
+            st4(a.hE + ((size_t)i * TM_KS + row) * TM_H + ncol, s_ix[cur][0][row] >= 0 ? acc[rb][0] : f4{0.f, 0.f, 0.f, 0.f});
+        }
+        mark(8);
+#else
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) st4(tB + chunk_off(16 * rb + m, c4), acc[rb][0]);
         mark(8);
@@ -916,6 +938,7 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
             st4(a.hE + ((size_t)i * TM_KS + row) * TM_H + 4 * c32, y);
         }
         mark(10);
+#endif
         cur ^= 1;
         // no barrier: tB is rewritten only after three more barriers, s_ix[cur^1] after one
     }

@@ -5,6 +5,7 @@
 #   tools/ab_msg_wave.sh run        (on the GPU box)        -> gpurun_out/${TAG:-r06}_ab_msg_wave.txt
 # Per variant: per-kernel HIP-event times of the bench batch (tools/ab_time.py) and, from the kernel's own counters, the shader clock
 # it ran at (TMPNN_MSG_PROF=1: cycle counter against the 100 MHz reference around one wavefront's loop, after 40 forwards).
+# and the loop cycles of all eight wavefronts of the first and the last workgroup (round 6: the 11 : 5 residue split, NOTEBOOK 10.3f).
 cd "$(dirname "$0")/.."
 L=thermompnn_amd/libtmpnn_mw
 case "$1" in
@@ -22,7 +23,7 @@ run)
     for n in shipped nolds nogelu nomfma nogelu_nomfma; do
       echo "## $n"
       TMPNN_LIB=${L}_$n.so python tools/ab_time.py $n
-      TMPNN_LIB=${L}_$n.so TMPNN_MSG_PROF=1 python tools/prof_run.py 2>&1 | grep "wave phases" | tail -1
+      TMPNN_LIB=${L}_$n.so TMPNN_MSG_PROF=1 python tools/prof_run.py 2>&1 | grep -E "wave (phases|loops)" | tail -2
     done
     echo "## 8-wavefront form again (alternation)"
     TMPNN_LIB=${L}_shipped.so TMPNN_MSG_WAVE_MIN=1000000 python tools/ab_time.py 8wavefront
