@@ -775,6 +775,25 @@ def test_config3_full_size_ragged_1024(engine, synthetic_weights):
         np.testing.assert_allclose(mine.cpu().numpy(), _oracle_table(synthetic_weights, p), atol=TOL_DDG, rtol=0)
 
 
+def test_message_pass_residue_split_is_batch_invariant(engine):
+    """Round 6: inside a workgroup of the wavefront-per-residue message pass the first-dispatched wavefront of a SIMD takes 11 sixteenths
+    of the SIMD's residues, its partner the rest (thermompnn_amd/csrc/tmpnn_msg.hip, TM_MSG_WAVE_OLD_16TH). Batches of n copies of one
+    L = 256 protein give every workgroup of a 256-CU device n residues (n = 20: 16 + a remainder for the 8-wavefront kernel): the splits
+    3:1, 4:2, 7:3 and 10:4 per SIMD. Every copy must equal the single-protein forward (fused small-launch forms) bit for bit — every residue
+    is computed exactly once, whichever wavefront takes it."""
+    g = load_golden("syn_L256")
+    p = packed_inputs(g)
+    single = engine.ssm_forward(p["X"], p["S"], p["mask"], p["ridx"], p["cenc"], p["offsets"])["ddg"]
+    L = p["L"]
+    for n in (16, 20, 24, 40, 56):
+        rep = lambda k: p[k].repeat(*([n] + [1] * (p[k].dim() - 1)))
+        offsets = torch.arange(0, (n + 1) * L, L, dtype=torch.int32)
+        ddg = engine.ssm_forward(rep("X"), rep("S"), rep("mask"), rep("ridx"), rep("cenc"), offsets, max_len=L)["ddg"]
+        assert ddg.shape[0] == n * L
+        for k in range(n):
+            assert torch.equal(ddg[k * L:(k + 1) * L], single), f"copy {k} of {n} differs from the single-protein forward"
+
+
 def test_config4_listed_mutations(engine, synthetic_weights):
     """BASELINE.json configs[3] on one rank: 300 Megascale-like proteins (L in [40, 72]: K_eff = min(48, L) < 48 for many)
     and an explicit list of 200 000 (protein, position, aa) triples drawn without replacement; the product path is
