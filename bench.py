@@ -133,7 +133,7 @@ def pmc_traffic(kernel, T):
     return None
 
 
-def live_pmc_traffic(patterns, timeout_s=150):
+def live_pmc_traffic(patterns, timeout_s=90):
     """HBM bytes per launch measured INSIDE this run (round 6; the round-5 review: the committed file is the builder's claim): two
     child processes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel trace only — the
     combination MI355X_MICROARCH.md prescribes) over tools/pmc_workload.py: three forwards of the bench batch (T = 16384) and a
