@@ -63,7 +63,8 @@ __global__ __launch_bounds__(512, 2) void enc_edge8_rp_kernel(EdgeArgsB a, unsig
         else return a.P + (size_t)jj * 256 + 128 + ncol;
     };
     constexpr int EPF = SP::EXACT ? 1 : TM_EDGE_PF;                      // B-fragment prefetch distance (three planes per fragment in bf16x3)
-    f4 b12r, b13r, g4r, be4r;
+    const f4 z4p = f4{0.f, 0.f, 0.f, 0.f};
+    f4 b12r = z4p, b13r = z4p, g4r = z4p, be4r = z4p;                    // (bf16x3 reads these four from LDS instead: s_par)
     if constexpr (SP::EXACT) {
         if (tid < 128) st4(&s_par[tid >> 5][4 * (tid & 31)], ld4((tid < 32 ? a.b12 : tid < 64 ? a.b13 : tid < 96 ? a.g3 : a.be3) + 4 * (tid & 31)));
     } else {

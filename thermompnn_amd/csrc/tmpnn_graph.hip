@@ -572,7 +572,7 @@ __device__ __forceinline__ void tm_glds16(const void *src, unsigned lds) {
 __device__ __forceinline__ void tm_glds4(const void *src, unsigned lds) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
 }
-// PROF: phase timing (s_memtime deltas of thread 0 of workgroup 0, summed over its tiles) into prof[0..7] — TMPNN_FEAT_PROF=1
+// PROF: phase timing (s_memtime deltas of thread 0 of workgroup 0, summed over its tiles) into prof[0..8] — TMPNN_FEAT_PROF=1
 // KNN (small launches, one tile per workgroup): the neighbour row of the workgroup's residue is computed HERE by wavefront 0
 // (knn_residue<4>: T <= #CUs <= 256, so every protein fits the register form) while the other seven load their weight fragments — one
 // launch less in front of a single protein (2.5 us of dispatch + the start-up latency of a kernel, tools/gap_probe.py).
@@ -590,29 +590,17 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
     };
     constexpr int PLB = TM_TILE * RBFP_ROWB;                 // bytes per RBF plane
     constexpr int TILEB = SP::NP * SPLIT_PLANE_BYTES;
-    static_assert(SP::NP * PLB >= TILEB, "the GEMM-2 planes are aliased on the RBF planes");
     __shared__ __attribute__((aligned(16))) char rbf[SP::NP * PLB];
-#ifndef TM_FEAT_DIRECT_STORE
-#define TM_FEAT_DIRECT_STORE 1
-#endif
-#if TM_FEAT_DIRECT_STORE
-    __shared__ __attribute__((aligned(16))) char s_tA[TILEB];           // GEMM 2's operand planes: their own tile, not the RBF planes
-#else
-    __shared__ __attribute__((aligned(16))) float tB[TM_TILE * TM_H];   // fp32 output tile
-#endif
+    // GEMM 2's operand planes: a tile of their own (until round 6 aliased on the RBF planes, with an fp32 output tile here — see the stores)
+    __shared__ __attribute__((aligned(16))) char s_tA[TILEB];
     __shared__ __attribute__((aligned(16))) float s_stat[TM_TILE][TM_STAT8_LD];
     __shared__ float s_atoms[TM_TILE][16];
     __shared__ float s_self[16];
     __shared__ float s_dist[TM_TILE][28];
     __shared__ int s_ix[2][2][TM_TILE];                      // [buffer][neighbour index | positional index][neighbour]: ONE array, one lane base
     __shared__ __attribute__((aligned(16))) float s_const[3][TM_H];   // W_e bias, LayerNorm gain / bias: read where used, not held (12 VGPRs)
-#if TM_FEAT_DIRECT_STORE
     char *tAp = s_tA;
-#else
-    char *tAp = rbf;
-#endif
     const int tid = tm_tid(), lane = tid & 63, wv = tid >> 6, m = lane & 15, q = lane >> 4;
-    const int c32 = lane & 31;
     const int ncol = 16 * wv + 4 * q, c4 = 4 * wv + q;
 
     // Weight fragments, resident for the whole launch (136 VGPRs). With fragment images (f16x2 handles) they arrive as coalesced
@@ -915,32 +903,18 @@ __global__ __launch_bounds__(512, 2) void featurize_split_kernel(FeatArgs a, uns
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[rb][0] = be;
         mma_tile_split<SP, 4, 1>(tAp, we, acc, lane);           // W_e (:1229)
-#if TM_FEAT_DIRECT_STORE
         // round 6: h_E rows leave from the accumulators — a wavefront's store covers 16 rows x 64 B (its 16 columns) — instead of crossing
-        // LDS into full 512-byte rows: one barrier and one LDS round trip per tile less; the operand planes of GEMM 2 have the tile the
-        // fp32 rows had, so the next tile's Gaussians (into the RBF planes, last read two barriers ago) need no barrier behind GEMM 2
+        // LDS into full 512-byte rows (an fp32 tile, one more barrier, 3 ds_read_b128 + 3 stores per lane): -2.3 %, profiles/r06_ab_feat_store.txt
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             const int row = 16 * rb + m;
             st4(a.hE + ((size_t)i * TM_KS + row) * TM_H + ncol, s_ix[cur][0][row] >= 0 ? acc[rb][0] : f4{0.f, 0.f, 0.f, 0.f});
         }
         mark(8);
-#else
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) st4(tB + chunk_off(16 * rb + m, c4), acc[rb][0]);
-        mark(8);
-        __syncthreads();                                       // tAp consumed (the next Gaussians overwrite it), tB complete
-        mark(9);
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int row = 6 * wv + 2 * it + (lane >> 5);
-            const f4 y = s_ix[cur][0][row] >= 0 ? ld4(tB + chunk_off(row, c32)) : f4{0.f, 0.f, 0.f, 0.f};
-            st4(a.hE + ((size_t)i * TM_KS + row) * TM_H + 4 * c32, y);
-        }
-        mark(10);
-#endif
         cur ^= 1;
-        // no barrier: tB is rewritten only after three more barriers, s_ix[cur^1] after one
+        // no barrier behind GEMM 2: the next tile's Gaussians and positional columns go into the RBF planes (last read by GEMM 1, two barriers
+        // ago), its DMA pieces into buffers publish() consumed before the last-but-one barrier; s_tA is rewritten after two more barriers,
+        // s_ix[cur ^ 1] (this tile's, read by the stores above) by publish() after one
     }
 }
 
@@ -1108,8 +1082,8 @@ int launch_featurize(const tmpnn_weights *w, const float *X, const int32_t *ridx
         else featurize_split_kernel<SplitH2, true><<<(int)(T < cap ? T : cap), 512, 0, st>>>(a, d_prof);
         unsigned long long h[16];
         (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "featurize phases (100 MHz ticks, wg 0): gauss %llu bar %llu gemm1+stats %llu publish %llu bar %llu ln+split %llu dist %llu bar %llu gemm2 %llu bar %llu store %llu\n",
-                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+        fprintf(stderr, "featurize phases (cycles, wg 0): gauss %llu bar %llu gemm1+stats %llu publish %llu bar %llu ln+split %llu dist %llu bar %llu gemm2+store %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
         tm_prof_end(st);
         return tm_check_launch("edge_featurize");
     }
